@@ -1,0 +1,206 @@
+"""Benchmark of the rasterizer hot path: train iters/sec (fwd+bwd rasterize) @1980x1080, 1M Gaussians.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config C3]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one forward + one backward of the drop-in GaussianRasterizer over one synthetic view
+(inputs resident in HBM).  With N > 1 every rank renders its own view of the replicated scene and
+the per-step parameter gradients (59 floats per Gaussian) are summed with one RCCL all-reduce per
+tensor; value = views per second over all ranks (weak scaling).  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, "gaussian-splatting_cc-comments_amd")
+for p in (ROOT, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+import gsr_scene  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def algorithmic_bytes(P, V, R, Rp, N, T, M):
+    """SURVEY.md section 8(d) per-stage algorithmic bytes (deg-3 SH: 4*3*M = 192 B)."""
+    sh = 12 * M
+    fwd = {
+        "preprocess": (44 * P + sh * V) + (8 * P + 67 * V),
+        "scan": 8 * P,
+        "duplicate_keys": 20 * P + 12 * R,
+        "sort": 24 * R,
+        "tile_ranges": 8 * R + 16 * T,
+        "render_forward": 8 * T + 40 * Rp + 20 * N,
+    }
+    bwd = {
+        "render_backward": 8 * T + 40 * R + 20 * N + 44 * V,
+        "gaussian_backward": 92 * V + (sh + 339) * V + 300 * P,
+    }
+    return fwd, bwd
+
+
+def cpu_baseline(scene, cam, D):
+    """The CPU oracle (a port: the reference has no CPU path and its CUDA sources cannot be built
+    here) timed on one full step of the same workload, all host cores via OpenMP."""
+    import numpy as np
+    from oracle import oracle
+    cores = os.cpu_count() or 1
+    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    t0 = time.time()
+    o = oracle.forward(scene.means3D.numpy(), scene.opacities.numpy(), cam.world_view_transform.numpy(),
+                       cam.full_proj_transform.numpy(), cam.camera_center.numpy(), scene.bg.numpy(), cam.image_width,
+                       cam.image_height, cam.tanfovx, cam.tanfovy, D, shs=scene.shs.numpy(), scales=scene.scales.numpy(),
+                       rotations=scene.rotations.numpy())
+    g = torch.Generator().manual_seed(1)
+    dpix = torch.randn(3, cam.image_height, cam.image_width, generator=g).numpy()
+    oracle.backward(o, dpix)
+    dt = time.time() - t0
+    return dict(value=1.0 / dt, unit="it/s", cores=cores, kind="port",
+                sample="1 full fwd+bwd step of the same workload (C oracle, OpenMP, all host cores)"), o
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="C3", choices=list(gsr_scene.CONFIGS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer, _C
+    _C.lib()  # fail loudly if the HIP library is missing
+
+    P, W, H, D, mu = gsr_scene.CONFIGS[args.config]
+    scene = gsr_scene.make_scene(P, mu, D, seed=0)          # replicated parameters
+    cam = gsr_scene.ring_camera(W, H, k=rank, n=max(world, 8)) if world > 1 else gsr_scene.make_camera(W, H)
+    M = scene.shs.shape[1]
+    to = lambda t: t.to(dev)
+    params = dict(means3D=to(scene.means3D).requires_grad_(True), shs=to(scene.shs).requires_grad_(True),
+                  opacities=to(scene.opacities).requires_grad_(True), scales=to(scene.scales).requires_grad_(True),
+                  rotations=to(scene.rotations).requires_grad_(True))
+    settings = GaussianRasterizationSettings(
+        image_height=H, image_width=W, tanfovx=cam.tanfovx, tanfovy=cam.tanfovy, bg=to(scene.bg), scale_modifier=1.0,
+        viewmatrix=to(cam.world_view_transform), projmatrix=to(cam.full_proj_transform), sh_degree=D,
+        campos=to(cam.camera_center), prefiltered=False, debug=False)
+    rasterizer = GaussianRasterizer(settings)
+    g = torch.Generator().manual_seed(1 + rank)
+    dpix = to(torch.randn(3, H, W, generator=g))
+    state = {}
+
+    def step():
+        for p in params.values():
+            p.grad = None
+        means2D = torch.zeros_like(params["means3D"], requires_grad=True)  # gaussian_renderer/__init__.py:37
+        color, radii = rasterizer(means3D=params["means3D"], means2D=means2D, **{k: v for k, v in params.items() if k != "means3D"})
+        color.backward(dpix)
+        if world > 1:  # view-parallel: sum the 59 floats/Gaussian of parameter gradients over ranks
+            works = [dist.all_reduce(p.grad, async_op=True) for p in params.values()]
+            for w_ in works:
+                w_.wait()
+        state["color"], state["radii"] = color, radii
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    _C.profile_begin()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    ktimes = _C.profile_end(capacity=64 * max(args.steps, 1))
+    if world > 1:
+        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    if rank == 0:
+        # workload statistics for the algorithmic byte counts
+        radii = state["radii"]
+        V = int((radii > 0).sum().item())
+        N, T = W * H, ((W + 15) // 16) * ((H + 15) // 16)
+        # R and R' (instances actually staged by the forward blend) from the state buffers
+        cap = {}
+        orig = _C.rasterize_gaussians
+
+        def spy(*a):
+            r = orig(*a)
+            cap["R"], cap["img"] = r[0], r[5]
+            return r
+        _C.rasterize_gaussians = spy
+        with torch.no_grad():
+            rasterizer(means3D=params["means3D"], means2D=torch.zeros_like(params["means3D"]),
+                       **{k: v for k, v in params.items() if k != "means3D"})
+        _C.rasterize_gaussians = orig
+        R = int(cap["R"])
+        il = _C.image_layout(W, H)
+        tmc = cap["img"][il.tile_max_contrib:il.tile_max_contrib + 4 * T].view(torch.int32)
+        rng = cap["img"][il.ranges:il.ranges + 8 * T].view(torch.int32).view(T, 2)
+        # forward stages whole 256-batches until every pixel of the tile is done
+        staged = torch.minimum(((tmc + 256) // 256) * 256, rng[:, 1] - rng[:, 0])
+        Rp = int(staged.clamp(min=0).sum().item())
+        fwd_b, bwd_b = algorithmic_bytes(P, V, R, Rp, N, T, M)
+        per_kernel = {}
+        for name, ms in ktimes:
+            per_kernel.setdefault(name, []).append(ms)
+        kern = {}
+        allb = dict(fwd_b, **bwd_b)
+        for name, v in per_kernel.items():
+            avg = sum(v) / len(v)
+            kern[name] = dict(ms=round(avg, 4), launches=len(v), algorithmic_bytes=allb.get(name),
+                              GBps=round(allb[name] / (avg * 1e-3) / 1e9, 1) if allb.get(name) and avg > 0 else None)
+        step_bytes = sum(fwd_b.values()) + sum(bwd_b.values())
+        ms_per_step = elapsed / args.steps * 1e3
+        dom = max(kern, key=lambda k: kern[k]["ms"]) if kern else None
+        roofline = None
+        if dom:
+            a = kern[dom]["GBps"] or 0.0
+            roofline = dict(kernel=dom, bound="hbm", achieved=a, peak=HBM_PEAK_GBS, unit="GB/s",
+                            frac=round(a / HBM_PEAK_GBS, 4), traffic=None,
+                            avg_launch_ms=kern[dom]["ms"], algorithmic_bytes_per_launch=kern[dom]["algorithmic_bytes"],
+                            step_algorithmic_bytes=step_bytes,
+                            step_GBps=round(step_bytes / (ms_per_step * 1e-3) / 1e9, 1),
+                            step_frac=round(step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
+        out = dict(metric="train iters/sec (fwd+bwd rasterize) @1980x1080, 1M Gaussians", value=round(world * args.steps / elapsed, 3),
+                   unit="it/s", n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(ms_per_step, 4),
+                   higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
+                   config=dict(workload=f"{args.config}: {P} Gaussians, SH deg {D}, {W}x{H}, mu={mu}, seed 0",
+                               P=P, V=V, R=R, R_staged_fwd=Rp, views_per_step=world,
+                               parallelism=f"view-parallel x{world}" if world > 1 else "single view"),
+                   roofline=roofline, kernels=kern)
+        if world == 1 and not args.no_cpu_baseline:
+            import numpy as np
+            cb, o = cpu_baseline(scene, cam, D)
+            out["cpu_baseline"] = cb
+            okm = (o["fragile"] == 0).reshape(H, W)
+            diff = np.abs(state["color"].detach().cpu().numpy() - o["color"])
+            out["image_L1_vs_oracle"] = float(diff.mean())
+            out["image_maxabs_vs_oracle_nonfragile"] = float(diff[:, okm].max())
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,406 @@
+// api.hip -- the C ABI of libgsr_hip.so (include/gsr.h): buffer layouts, stage orchestration,
+// error reporting.  Orchestration replaces CudaRasterizer::Rasterizer::{forward,backward,markVisible}
+// (cuda_rasterizer/rasterizer_impl.cu:162-174, 227-411, 416-518).
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "gsr_internal.h"
+
+// ---- errors ------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+int gsr_fail(int code, const char* fmt, ...)
+{
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(g_err, sizeof g_err, fmt, ap);
+	va_end(ap);
+	return code;
+}
+
+int gsr_check_hip(hipError_t e, const char* what)
+{
+	if (e == hipSuccess) return GSR_OK;
+	return gsr_fail(GSR_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
+}
+
+int gsr_stage_done(hipStream_t s, int debug, const char* stage)
+{
+	hipError_t e = hipGetLastError();
+	if (e != hipSuccess) return gsr_fail(GSR_ERR_HIP, "launch of %s failed: %s", stage, hipGetErrorString(e));
+	if (debug) {  // CHECK_CUDA semantics, auxiliary.h:177-184
+		e = hipStreamSynchronize(s);
+		if (e != hipSuccess) return gsr_fail(GSR_ERR_HIP, "[HIP ERROR] in stage %s: %s", stage, hipGetErrorString(e));
+	}
+	return GSR_OK;
+}
+
+extern "C" const char* gsr_last_error(void) { return g_err; }
+extern "C" const char* gsr_version(void) { return "gsr-hip gfx950 r1"; }
+
+// ---- per-kernel event profiling ----------------------------------------------------------------
+// Events come from a pool that only grows, so recording inside a timed region costs two
+// hipEventRecord per stage and no allocation after the first step.
+struct ProfEntry { const char* name; hipEvent_t a, b; };
+// Process-global (PyTorch runs backward on its own autograd thread), guarded by a mutex.
+static std::mutex g_prof_mu;
+static bool g_prof_on = false;
+static std::vector<ProfEntry>* g_prof = nullptr;
+static size_t g_prof_used = 0;
+
+void gsr_prof_mark_begin(hipStream_t s, const char* name)
+{
+	std::lock_guard<std::mutex> lk(g_prof_mu);
+	if (!g_prof_on) return;
+	if (g_prof_used == g_prof->size()) {
+		ProfEntry e;
+		e.name = name;
+		(void)hipEventCreate(&e.a);
+		(void)hipEventCreate(&e.b);
+		g_prof->push_back(e);
+	}
+	ProfEntry& e = (*g_prof)[g_prof_used++];
+	e.name = name;
+	(void)hipEventRecord(e.a, s);
+}
+
+void gsr_prof_mark_end(hipStream_t s)
+{
+	std::lock_guard<std::mutex> lk(g_prof_mu);
+	if (!g_prof_on || g_prof_used == 0) return;
+	(void)hipEventRecord((*g_prof)[g_prof_used - 1].b, s);
+}
+
+extern "C" int gsr_profile_begin(void)
+{
+	std::lock_guard<std::mutex> lk(g_prof_mu);
+	if (!g_prof) g_prof = new std::vector<ProfEntry>();
+	g_prof_used = 0;
+	g_prof_on = true;
+	return GSR_OK;
+}
+
+extern "C" int gsr_profile_end(gsr_kernel_time* out, int capacity)
+{
+	std::lock_guard<std::mutex> lk(g_prof_mu);
+	if (!g_prof_on) return 0;
+	g_prof_on = false;
+	int n = 0;
+	for (size_t k = 0; k < g_prof_used; k++) {
+		ProfEntry& e = (*g_prof)[k];
+		(void)hipEventSynchronize(e.b);
+		float ms = 0.f;
+		(void)hipEventElapsedTime(&ms, e.a, e.b);
+		if (n < capacity) { out[n].name = e.name; out[n].ms = ms; n++; }
+	}
+	g_prof_used = 0;
+	return n;
+}
+
+// ---- layouts -----------------------------------------------------------------------------------
+extern "C" int gsr_geometry_layout_of(int P, gsr_geometry_layout* o)
+{
+	if (P < 0 || !o) return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "gsr_geometry_layout_of: bad arguments");
+	const size_t n = (size_t)P;
+	const size_t nb = (n + GSR_PREPROCESS_BLOCK - 1) / GSR_PREPROCESS_BLOCK;
+	size_t off = 0;
+	o->splat = off;         off = gsr_align_up(off + n * sizeof(GsrSplat));
+	o->depths = off;        off = gsr_align_up(off + n * 4);
+	o->tiles_touched = off; off = gsr_align_up(off + n * 4);
+	o->point_offsets = off; off = gsr_align_up(off + n * 4);
+	o->clamped = off;       off = gsr_align_up(off + n);
+	o->status = off;        off = gsr_align_up(off + 4 * 4);
+	o->scan_temp = off;     off = gsr_align_up(off + nb * 4);
+	o->total = off;
+	return GSR_OK;
+}
+
+extern "C" int gsr_image_layout_of(int W, int H, gsr_image_layout* o)
+{
+	if (W < 0 || H < 0 || !o) return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "gsr_image_layout_of: bad arguments");
+	const size_t N = (size_t)W * H, T = (size_t)gsr_grid_x(W) * gsr_grid_y(H);
+	size_t off = 0;
+	o->final_T = off;          off = gsr_align_up(off + N * 4);
+	o->n_contrib = off;        off = gsr_align_up(off + N * 4);
+	o->ranges = off;           off = gsr_align_up(off + T * 8);
+	o->tile_max_contrib = off; off = gsr_align_up(off + T * 4);
+	o->total = off;
+	return GSR_OK;
+}
+
+extern "C" int gsr_binning_layout_of(int P, int64_t R, int W, int H, gsr_binning_layout* o)
+{
+	(void)P; (void)W; (void)H;
+	if (R < 0 || !o) return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "gsr_binning_layout_of: bad arguments");
+	const size_t n = (size_t)R;
+	size_t off = 0;
+	o->point_list = off;          off = gsr_align_up(off + n * 4);
+	o->point_list_unsorted = off; off = gsr_align_up(off + n * 4);
+	o->keys = off;                off = gsr_align_up(off + n * 8);
+	o->keys_unsorted = off;       off = gsr_align_up(off + n * 8);
+	o->sort_temp_bytes = gsr_sort_temp_bytes(R);
+	o->sort_temp = off;           off = gsr_align_up(off + o->sort_temp_bytes);
+	o->total = off;
+	return GSR_OK;
+}
+
+extern "C" size_t gsr_geometry_bytes(int P)
+{
+	gsr_geometry_layout l;
+	return gsr_geometry_layout_of(P, &l) == GSR_OK ? l.total : 0;
+}
+extern "C" size_t gsr_image_bytes(int W, int H)
+{
+	gsr_image_layout l;
+	return gsr_image_layout_of(W, H, &l) == GSR_OK ? l.total : 0;
+}
+extern "C" size_t gsr_binning_bytes(int P, int64_t R, int W, int H)
+{
+	gsr_binning_layout l;
+	return gsr_binning_layout_of(P, R, W, H, &l) == GSR_OK ? l.total : 0;
+}
+extern "C" size_t gsr_backward_scratch_bytes(int P, int64_t R)
+{
+	(void)P;
+	if (R < 0) return 0;
+	return gsr_align_up((size_t)R * sizeof(GsrGradSlot)) + gsr_align_up((size_t)R);
+}
+
+GsrGeometry gsr_geometry_view(void* blob, int P)
+{
+	gsr_geometry_layout l;
+	gsr_geometry_layout_of(P, &l);
+	char* b = (char*)blob;
+	GsrGeometry g;
+	g.splat = (GsrSplat*)(b + l.splat);
+	g.depths = (float*)(b + l.depths);
+	g.tiles_touched = (uint32_t*)(b + l.tiles_touched);
+	g.point_offsets = (uint32_t*)(b + l.point_offsets);
+	g.clamped = (uint8_t*)(b + l.clamped);
+	g.status = (uint32_t*)(b + l.status);
+	g.block_sums = (uint32_t*)(b + l.scan_temp);
+	return g;
+}
+
+GsrImage gsr_image_view(void* blob, int W, int H)
+{
+	gsr_image_layout l;
+	gsr_image_layout_of(W, H, &l);
+	char* b = (char*)blob;
+	GsrImage im;
+	im.final_T = (float*)(b + l.final_T);
+	im.n_contrib = (uint32_t*)(b + l.n_contrib);
+	im.ranges = (uint2*)(b + l.ranges);
+	im.tile_max_contrib = (uint32_t*)(b + l.tile_max_contrib);
+	return im;
+}
+
+GsrBinning gsr_binning_view(void* blob, int P, int64_t R, int W, int H)
+{
+	gsr_binning_layout l;
+	gsr_binning_layout_of(P, R, W, H, &l);
+	char* b = (char*)blob;
+	GsrBinning bn;
+	bn.point_list = (uint32_t*)(b + l.point_list);
+	bn.point_list_unsorted = (uint32_t*)(b + l.point_list_unsorted);
+	bn.keys = (uint64_t*)(b + l.keys);
+	bn.keys_unsorted = (uint64_t*)(b + l.keys_unsorted);
+	bn.sort_temp = (void*)(b + l.sort_temp);
+	bn.sort_temp_bytes = l.sort_temp_bytes;
+	return bn;
+}
+
+// rasterizer_impl.cu:37-52
+extern "C" uint32_t gsr_get_higher_msb(uint32_t n)
+{
+	uint32_t msb = sizeof(n) * 4;
+	uint32_t step = msb;
+	while (step > 1) {
+		step /= 2;
+		if (n >> msb) msb += step; else msb -= step;
+	}
+	if (n >> msb) msb++;
+	return msb;
+}
+
+static bool aligned16(const void* p) { return ((uintptr_t)p & 15u) == 0; }
+
+// ---- forward, stage 1 --------------------------------------------------------------------------
+extern "C" int gsr_forward_preprocess(int P, int D, int M, int width, int height, const float* means3D,
+                                      const float* shs, const float* colors_precomp, const float* opacities,
+                                      const float* scales, float scale_modifier, const float* rotations,
+                                      const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
+                                      const float* cam_pos, float tan_fovx, float tan_fovy, int prefiltered,
+                                      int* radii, void* geometry, int64_t* num_rendered_host, void* stream, int debug)
+{
+	g_err[0] = 0;
+	hipStream_t s = (hipStream_t)stream;
+	if (!num_rendered_host) return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "num_rendered_host is NULL");
+	*num_rendered_host = 0;
+	if (P < 0 || width <= 0 || height <= 0) return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "bad P / image size");
+	if (P == 0) return GSR_OK;  // rasterize_points.cu:94: nothing is launched for an empty scene
+	if (!means3D || !opacities || !viewmatrix || !projmatrix || !radii || !geometry)
+		return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "gsr_forward_preprocess: required pointer is NULL");
+	if (!colors_precomp && !shs)  // rasterizer_impl.cu:281-284
+		return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "For non-RGB, provide precomputed Gaussian colors!");
+	if (!colors_precomp && (M <= 0 || (D + 1) * (D + 1) > M || D < 0 || D > 3 || !cam_pos))
+		return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "SH degree %d needs %d coefficients, M = %d", D, (D + 1) * (D + 1), M);
+	if (!cov3D_precomp && (!scales || !rotations))
+		return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "provide scales+rotations or cov3D_precomp");
+	if (width > 65535 * GSR_TILE_X || height > 65535 * GSR_TILE_Y)
+		return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "image too large for 16-bit tile coordinates");
+	if (!aligned16(geometry)) return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "geometry buffer must be 16-byte aligned");
+
+	GsrPreprocessArgs a;
+	a.P = P; a.D = D; a.M = M; a.W = width; a.H = height;
+	a.means3D = means3D; a.shs = shs; a.colors_precomp = colors_precomp; a.opacities = opacities;
+	a.scales = scales; a.scale_modifier = scale_modifier; a.rotations = rotations; a.cov3D_precomp = cov3D_precomp;
+	a.viewmatrix = viewmatrix; a.projmatrix = projmatrix; a.cam_pos = cam_pos;
+	a.tan_fovx = tan_fovx; a.tan_fovy = tan_fovy;
+	a.focal_y = height / (2.0f * tan_fovy);  // rasterizer_impl.cu:251-252
+	a.focal_x = width / (2.0f * tan_fovx);
+	a.prefiltered = prefiltered;
+	a.radii = radii;
+	a.g = gsr_geometry_view(geometry, P);
+
+	int rc;
+	if ((rc = gsr_check_hip(hipMemsetAsync(a.g.status, 0, 16, s), "hipMemsetAsync(status)"))) return rc;
+	{
+		GsrProfScope p(s, "preprocess");
+		gsr_launch_preprocess(a, s);
+	}
+	if ((rc = gsr_stage_done(s, debug, "preprocess"))) return rc;
+	{
+		GsrProfScope p(s, "scan");
+		gsr_launch_scan_block_sums(a.g, P, s);
+		gsr_launch_finalize_offsets(a.g, P, s);
+	}
+	if ((rc = gsr_stage_done(s, debug, "scan"))) return rc;
+
+	uint32_t status_host[2] = {0, 0};
+	if ((rc = gsr_check_hip(hipMemcpyAsync(status_host, a.g.status, 8, hipMemcpyDeviceToHost, s), "hipMemcpyAsync(num_rendered)"))) return rc;
+	if ((rc = gsr_check_hip(hipStreamSynchronize(s), "hipStreamSynchronize(preprocess)"))) return rc;
+	if (status_host[0] & 1u)
+		return gsr_fail(GSR_ERR_PREFILTERED, "Point is filtered although prefiltered is set. This shouldn't happen!");
+	*num_rendered_host = (int64_t)status_host[1];
+	return GSR_OK;
+}
+
+// ---- forward, stage 2 --------------------------------------------------------------------------
+extern "C" int gsr_forward_render(int P, int64_t R, int width, int height, const float* background,
+                                  const int* radii, void* geometry, void* binning, void* image, float* out_color,
+                                  void* stream, int debug)
+{
+	g_err[0] = 0;
+	hipStream_t s = (hipStream_t)stream;
+	if (P < 0 || R < 0 || width <= 0 || height <= 0) return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "bad sizes");
+	if (P == 0) return GSR_OK;  // image stays as allocated by the caller (zero-filled in the reference)
+	if (!background || !geometry || !image || !out_color || (R > 0 && !binning))
+		return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "gsr_forward_render: required pointer is NULL");
+	if (!aligned16(geometry) || !aligned16(image) || !aligned16(binning))
+		return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "state buffers must be 16-byte aligned");
+	if (R > 0xffffffffLL) return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "num_rendered exceeds 32-bit offsets");
+
+	GsrGeometry g = gsr_geometry_view(geometry, P);
+	GsrImage im = gsr_image_view(image, width, height);
+	const int ntiles = gsr_grid_x(width) * gsr_grid_y(height);
+	int rc;
+	GsrBinning b;
+	memset(&b, 0, sizeof b);
+	if (R > 0) {
+		b = gsr_binning_view(binning, P, R, width, height);
+		{
+			GsrProfScope p(s, "duplicate_keys");
+			gsr_launch_duplicate_keys(g, radii, P, width, height, b, s);
+		}
+		if ((rc = gsr_stage_done(s, debug, "duplicate_keys"))) return rc;
+		const int bit = (int)gsr_get_higher_msb((uint32_t)ntiles);
+		{
+			GsrProfScope p(s, "sort");
+			if ((rc = gsr_sort_pairs(b, R, 32 + bit, s))) return rc;
+		}
+		if ((rc = gsr_stage_done(s, debug, "sort"))) return rc;
+	}
+	{
+		GsrProfScope p(s, "tile_ranges");
+		gsr_launch_tile_ranges(b.keys, R, im.ranges, ntiles, s);
+	}
+	if ((rc = gsr_stage_done(s, debug, "tile_ranges"))) return rc;
+	{
+		GsrProfScope p(s, "render_forward");
+		gsr_launch_render_forward(width, height, im, b.point_list, g.splat, background, out_color, s);
+	}
+	return gsr_stage_done(s, debug, "render_forward");
+}
+
+// ---- backward ----------------------------------------------------------------------------------
+extern "C" int gsr_backward(int P, int D, int M, int64_t R, int width, int height, const float* background,
+                            const float* means3D, const float* shs, const float* colors_precomp,
+                            const float* scales, float scale_modifier, const float* rotations,
+                            const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
+                            const float* cam_pos, float tan_fovx, float tan_fovy, const int* radii, void* geometry,
+                            void* binning, void* image, void* scratch, const float* dL_dpix, float* dL_dmean2D,
+                            float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D,
+                            float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, void* stream,
+                            int debug)
+{
+	g_err[0] = 0;
+	hipStream_t s = (hipStream_t)stream;
+	if (P < 0 || R < 0 || width <= 0 || height <= 0) return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "bad sizes");
+	if (P == 0) return GSR_OK;
+	if (!background || !means3D || !viewmatrix || !projmatrix || !radii || !geometry || !image || !dL_dpix ||
+	    !dL_dmean2D || !dL_dconic || !dL_dopacity || !dL_dcolor || !dL_dmean3D || !dL_dcov3D || !dL_dscale || !dL_drot ||
+	    (R > 0 && (!binning || !scratch)) || (M > 0 && !dL_dsh))
+		return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "gsr_backward: required pointer is NULL");
+	if (!aligned16(geometry) || !aligned16(image) || !aligned16(binning) || !aligned16(scratch))
+		return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "state buffers must be 16-byte aligned");
+
+	GsrGeometry g = gsr_geometry_view(geometry, P);
+	GsrImage im = gsr_image_view(image, width, height);
+	GsrGradSlot* slots = (GsrGradSlot*)scratch;
+	uint8_t* slot_valid = (uint8_t*)scratch + gsr_align_up((size_t)R * sizeof(GsrGradSlot));
+	int rc;
+	if (R > 0) {
+		GsrBinning b = gsr_binning_view(binning, P, R, width, height);
+		{
+			GsrProfScope p(s, "render_backward");
+			if ((rc = gsr_check_hip(hipMemsetAsync(slot_valid, 0, (size_t)R, s), "hipMemsetAsync(slot_valid)"))) return rc;
+			gsr_launch_render_backward(width, height, im, b.point_list, g.splat, background, dL_dpix, slots, slot_valid, s);
+		}
+		if ((rc = gsr_stage_done(s, debug, "render_backward"))) return rc;
+	}
+
+	GsrGaussianBackwardArgs a;
+	a.P = P; a.D = D; a.M = M; a.W = width; a.H = height;
+	a.means3D = means3D; a.shs = shs; a.colors_precomp = colors_precomp; a.scales = scales;
+	a.scale_modifier = scale_modifier; a.rotations = rotations; a.cov3D_precomp = cov3D_precomp;
+	a.viewmatrix = viewmatrix; a.projmatrix = projmatrix; a.cam_pos = cam_pos;
+	a.tan_fovx = tan_fovx; a.tan_fovy = tan_fovy;
+	a.focal_y = height / (2.0f * tan_fovy);
+	a.focal_x = width / (2.0f * tan_fovx);
+	a.radii = radii; a.g = g; a.slots = slots; a.slot_valid = slot_valid;
+	a.dL_dmean2D = dL_dmean2D; a.dL_dconic = dL_dconic; a.dL_dopacity = dL_dopacity; a.dL_dcolor = dL_dcolor;
+	a.dL_dmean3D = dL_dmean3D; a.dL_dcov3D = dL_dcov3D; a.dL_dsh = dL_dsh; a.dL_dscale = dL_dscale; a.dL_drot = dL_drot;
+	{
+		GsrProfScope p(s, "gaussian_backward");
+		gsr_launch_gaussian_backward(a, s);
+	}
+	return gsr_stage_done(s, debug, "gaussian_backward");
+}
+
+extern "C" int gsr_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,
+                                uint8_t* present, void* stream)
+{
+	g_err[0] = 0;
+	(void)projmatrix;
+	if (P < 0) return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "bad P");
+	if (P == 0) return GSR_OK;
+	if (!means3D || !viewmatrix || !present) return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "gsr_mark_visible: NULL pointer");
+	gsr_launch_mark_visible(P, means3D, viewmatrix, present, (hipStream_t)stream);
+	return gsr_stage_done((hipStream_t)stream, 0, "mark_visible");
+}

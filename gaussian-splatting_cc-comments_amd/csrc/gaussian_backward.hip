@@ -1,0 +1,249 @@
+// gaussian_backward.hip -- per-Gaussian backward (compiled with -ffp-contract=off).
+//
+// Fuses, in one pass over P: the fixed-order sum of a Gaussian's per-tile gradient slots (what
+// the reference accumulates with atomics in backward.cu:561-598), computeCov2DCUDA
+// (backward.cu:144-277), preprocessCUDA backward (backward.cu:349-399) with its SH
+// (backward.cu:20-139) and covariance (backward.cu:281-345) parts, and the zero fill of
+// rasterize_points.cu:168-178: every output element is written exactly once.
+#include "gsr_internal.h"
+
+__device__ __forceinline__ GsrVec3 gsr_dnormvdv(GsrVec3 v, GsrVec3 dv)  // auxiliary.h:109-120
+{
+	float sum2 = v.x * v.x + v.y * v.y + v.z * v.z;
+	float invsum32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
+	GsrVec3 r;
+	r.x = ((+sum2 - v.x * v.x) * dv.x - v.y * v.x * dv.y - v.z * v.x * dv.z) * invsum32;
+	r.y = (-v.x * v.y * dv.x + (sum2 - v.y * v.y) * dv.y - v.z * v.y * dv.z) * invsum32;
+	r.z = (-v.x * v.z * dv.x - v.y * v.z * dv.y + (sum2 - v.z * v.z) * dv.z) * invsum32;
+	return r;
+}
+
+// backward.cu:20-139; writes dL_dsh rows [0, (D+1)^2) and zeros the rest up to M
+__device__ __forceinline__ void gsr_sh_backward(int deg, int M, GsrVec3 pos, const float* campos, const float* sh,
+                                                uint8_t clamp_bits, const float* dL_dcolor, float* dL_dmean,
+                                                float* dL_dsh)
+{
+	GsrVec3 dir_orig = {pos.x - campos[0], pos.y - campos[1], pos.z - campos[2]};
+	float len = sqrtf(dir_orig.x * dir_orig.x + dir_orig.y * dir_orig.y + dir_orig.z * dir_orig.z);
+	float x = dir_orig.x / len, y = dir_orig.y / len, z = dir_orig.z / len;
+	float dd0 = 0.f, dd1 = 0.f, dd2 = 0.f;
+	const int used = (deg + 1) * (deg + 1);
+#pragma unroll
+	for (int ch = 0; ch < 3; ch++) {
+#define SH(k) sh[(k) * 3 + ch]
+#define DSH(k) dL_dsh[(k) * 3 + ch]
+		const float g = dL_dcolor[ch] * (((clamp_bits >> ch) & 1) ? 0.f : 1.f);
+		float dRGBdx = 0, dRGBdy = 0, dRGBdz = 0;
+		DSH(0) = GSR_SH_C0 * g;
+		if (deg > 0) {
+			DSH(1) = (-GSR_SH_C1 * y) * g;
+			DSH(2) = (GSR_SH_C1 * z) * g;
+			DSH(3) = (-GSR_SH_C1 * x) * g;
+			dRGBdx = -GSR_SH_C1 * SH(3);
+			dRGBdy = -GSR_SH_C1 * SH(1);
+			dRGBdz = GSR_SH_C1 * SH(2);
+			if (deg > 1) {
+				float xx = x * x, yy = y * y, zz = z * z;
+				float xy = x * y, yz = y * z, xz = x * z;
+				DSH(4) = (GSR_SH_C2[0] * xy) * g;
+				DSH(5) = (GSR_SH_C2[1] * yz) * g;
+				DSH(6) = (GSR_SH_C2[2] * (2.f * zz - xx - yy)) * g;
+				DSH(7) = (GSR_SH_C2[3] * xz) * g;
+				DSH(8) = (GSR_SH_C2[4] * (xx - yy)) * g;
+				dRGBdx += GSR_SH_C2[0] * y * SH(4) + GSR_SH_C2[2] * 2.f * -x * SH(6) + GSR_SH_C2[3] * z * SH(7) + GSR_SH_C2[4] * 2.f * x * SH(8);
+				dRGBdy += GSR_SH_C2[0] * x * SH(4) + GSR_SH_C2[1] * z * SH(5) + GSR_SH_C2[2] * 2.f * -y * SH(6) + GSR_SH_C2[4] * 2.f * -y * SH(8);
+				dRGBdz += GSR_SH_C2[1] * y * SH(5) + GSR_SH_C2[2] * 2.f * 2.f * z * SH(6) + GSR_SH_C2[3] * x * SH(7);
+				if (deg > 2) {
+					DSH(9) = (GSR_SH_C3[0] * y * (3.f * xx - yy)) * g;
+					DSH(10) = (GSR_SH_C3[1] * xy * z) * g;
+					DSH(11) = (GSR_SH_C3[2] * y * (4.f * zz - xx - yy)) * g;
+					DSH(12) = (GSR_SH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy)) * g;
+					DSH(13) = (GSR_SH_C3[4] * x * (4.f * zz - xx - yy)) * g;
+					DSH(14) = (GSR_SH_C3[5] * z * (xx - yy)) * g;
+					DSH(15) = (GSR_SH_C3[6] * x * (xx - 3.f * yy)) * g;
+					dRGBdx += (GSR_SH_C3[0] * SH(9) * 3.f * 2.f * xy + GSR_SH_C3[1] * SH(10) * yz + GSR_SH_C3[2] * SH(11) * -2.f * xy +
+					           GSR_SH_C3[3] * SH(12) * -3.f * 2.f * xz + GSR_SH_C3[4] * SH(13) * (-3.f * xx + 4.f * zz - yy) +
+					           GSR_SH_C3[5] * SH(14) * 2.f * xz + GSR_SH_C3[6] * SH(15) * 3.f * (xx - yy));
+					dRGBdy += (GSR_SH_C3[0] * SH(9) * 3.f * (xx - yy) + GSR_SH_C3[1] * SH(10) * xz +
+					           GSR_SH_C3[2] * SH(11) * (-3.f * yy + 4.f * zz - xx) + GSR_SH_C3[3] * SH(12) * -3.f * 2.f * yz +
+					           GSR_SH_C3[4] * SH(13) * -2.f * xy + GSR_SH_C3[5] * SH(14) * -2.f * yz +
+					           GSR_SH_C3[6] * SH(15) * -3.f * 2.f * xy);
+					dRGBdz += (GSR_SH_C3[1] * SH(10) * xy + GSR_SH_C3[2] * SH(11) * 4.f * 2.f * yz +
+					           GSR_SH_C3[3] * SH(12) * 3.f * (2.f * zz - xx - yy) + GSR_SH_C3[4] * SH(13) * 4.f * 2.f * xz +
+					           GSR_SH_C3[5] * SH(14) * (xx - yy));
+				}
+			}
+		}
+		for (int k = used; k < M; k++) DSH(k) = 0.f;
+#undef SH
+#undef DSH
+		dd0 += dRGBdx * g; dd1 += dRGBdy * g; dd2 += dRGBdz * g;
+	}
+	GsrVec3 ddir = {dd0, dd1, dd2};
+	GsrVec3 dm = gsr_dnormvdv(dir_orig, ddir);
+	dL_dmean[0] += dm.x; dL_dmean[1] += dm.y; dL_dmean[2] += dm.z;
+}
+
+// backward.cu:281-345
+__device__ __forceinline__ void gsr_cov3d_backward(const float* scale, float mod, const float* rot,
+                                                   const float* dL_dcov3D, float* dL_dscale, float* dL_drot)
+{
+	const float r = rot[0], x = rot[1], y = rot[2], z = rot[3];
+	GsrMat3 R = gsr_build_R(r, x, y, z);
+	const float s[3] = {mod * scale[0], mod * scale[1], mod * scale[2]};
+	GsrMat3 S = gsr_diag3(s[0], s[1], s[2]);
+	GsrMat3 M = gsr_mat3_mul(S, R);
+	GsrMat3 dS;
+	dS.m[0][0] = dL_dcov3D[0]; dS.m[0][1] = 0.5f * dL_dcov3D[1]; dS.m[0][2] = 0.5f * dL_dcov3D[2];
+	dS.m[1][0] = 0.5f * dL_dcov3D[1]; dS.m[1][1] = dL_dcov3D[3]; dS.m[1][2] = 0.5f * dL_dcov3D[4];
+	dS.m[2][0] = 0.5f * dL_dcov3D[2]; dS.m[2][1] = 0.5f * dL_dcov3D[4]; dS.m[2][2] = dL_dcov3D[5];
+	GsrMat3 M2;
+#pragma unroll
+	for (int c = 0; c < 3; c++)
+#pragma unroll
+		for (int w = 0; w < 3; w++) M2.m[c][w] = 2.0f * M.m[c][w];
+	GsrMat3 dL_dM = gsr_mat3_mul(M2, dS);
+	GsrMat3 Rt = gsr_mat3_transpose(R);
+	GsrMat3 dMt = gsr_mat3_transpose(dL_dM);
+#pragma unroll
+	for (int k = 0; k < 3; k++)
+		dL_dscale[k] = Rt.m[k][0] * dMt.m[k][0] + Rt.m[k][1] * dMt.m[k][1] + Rt.m[k][2] * dMt.m[k][2];
+#pragma unroll
+	for (int k = 0; k < 3; k++)
+#pragma unroll
+		for (int w = 0; w < 3; w++) dMt.m[k][w] *= s[k];
+#define Dm(a, b) dMt.m[a][b]
+	dL_drot[0] = 2 * z * (Dm(0, 1) - Dm(1, 0)) + 2 * y * (Dm(2, 0) - Dm(0, 2)) + 2 * x * (Dm(1, 2) - Dm(2, 1));
+	dL_drot[1] = 2 * y * (Dm(1, 0) + Dm(0, 1)) + 2 * z * (Dm(2, 0) + Dm(0, 2)) + 2 * r * (Dm(1, 2) - Dm(2, 1)) - 4 * x * (Dm(2, 2) + Dm(1, 1));
+	dL_drot[2] = 2 * x * (Dm(1, 0) + Dm(0, 1)) + 2 * r * (Dm(2, 0) - Dm(0, 2)) + 2 * z * (Dm(1, 2) + Dm(2, 1)) - 4 * y * (Dm(2, 2) + Dm(0, 0));
+	dL_drot[3] = 2 * r * (Dm(0, 1) - Dm(1, 0)) + 2 * x * (Dm(2, 0) + Dm(0, 2)) + 2 * y * (Dm(1, 2) + Dm(2, 1)) - 4 * z * (Dm(1, 1) + Dm(0, 0));
+#undef Dm
+}
+
+__global__ void __launch_bounds__(256) gsr_gaussian_backward_kernel(GsrGaussianBackwardArgs a)
+{
+	const int idx = blockIdx.x * 256 + threadIdx.x;
+	if (idx >= a.P) return;
+	const int M = a.M;
+
+	float dmean2D[3] = {0.f, 0.f, 0.f}, dconic[4] = {0.f, 0.f, 0.f, 0.f}, dop = 0.f, dcolor[3] = {0.f, 0.f, 0.f};
+	float dmean3D[3] = {0.f, 0.f, 0.f}, dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+	float dscale[3] = {0.f, 0.f, 0.f}, drot[4] = {0.f, 0.f, 0.f, 0.f};
+	float* dsh = a.dL_dsh ? a.dL_dsh + (size_t)idx * M * 3 : nullptr;
+	const bool visible = a.radii[idx] > 0;
+
+	if (visible) {
+		// ---- fixed-order sum of this Gaussian's (Gaussian,tile) slots ----
+		const uint32_t tiles = a.g.tiles_touched[idx];
+		const uint32_t base = a.g.splat[idx].slot_base;
+		for (uint32_t k = 0; k < tiles; k++) {
+			if (!a.slot_valid[base + k]) continue;
+			const float4* sl = reinterpret_cast<const float4*>(a.slots + base + k);
+			const float4 s0 = sl[0], s1 = sl[1];
+			const float s2 = sl[2].x;
+			dmean2D[0] += s0.x; dmean2D[1] += s0.y;
+			dconic[0] += s0.z; dconic[1] += s0.w; dconic[3] += s1.x;
+			dop += s1.y;
+			dcolor[0] += s1.z; dcolor[1] += s1.w; dcolor[2] += s2;
+		}
+
+		// ---- computeCov2DCUDA, backward.cu:144-277 ----
+		float cov3D[6];
+		float sc[3] = {0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
+		if (a.cov3D_precomp) {
+#pragma unroll
+			for (int k = 0; k < 6; k++) cov3D[k] = a.cov3D_precomp[6 * (size_t)idx + k];
+		} else {
+			sc[0] = a.scales[3 * idx]; sc[1] = a.scales[3 * idx + 1]; sc[2] = a.scales[3 * idx + 2];
+			q[0] = a.rotations[4 * idx]; q[1] = a.rotations[4 * idx + 1]; q[2] = a.rotations[4 * idx + 2]; q[3] = a.rotations[4 * idx + 3];
+			gsr_cov3d(sc, a.scale_modifier, q, cov3D);  // recomputed: identical bits to the forward's
+		}
+		const GsrVec3 mean = {a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]};
+		const float dcx = dconic[0], dcy = dconic[1], dcz = dconic[3];
+		GsrCov2D c2;
+		gsr_cov2d(mean, a.focal_x, a.focal_y, a.tan_fovx, a.tan_fovy, cov3D, a.viewmatrix, c2);
+		const float h_x = a.focal_x, h_y = a.focal_y;
+		const float x_grad_mul = (c2.txtz < -c2.limx || c2.txtz > c2.limx) ? 0.f : 1.f;
+		const float y_grad_mul = (c2.tytz < -c2.limy || c2.tytz > c2.limy) ? 0.f : 1.f;
+		const GsrMat3& T = c2.T;
+		const GsrMat3& Wm = c2.W;
+		const GsrMat3& Vrk = c2.Vrk;
+		const GsrVec3 t = c2.t;
+		const float ca = c2.a, cb = c2.b, cc = c2.c;
+		const float denom = ca * cc - cb * cb;
+		float dL_da = 0, dL_db = 0, dL_dc = 0;
+		const float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
+		if (denom2inv != 0) {
+			dL_da = denom2inv * (-cc * cc * dcx + 2 * cb * cc * dcy + (denom - ca * cc) * dcz);
+			dL_dc = denom2inv * (-ca * ca * dcz + 2 * ca * cb * dcy + (denom - ca * cc) * dcx);
+			dL_db = denom2inv * 2 * (cb * cc * dcx - (denom + 2 * cb * cb) * dcy + ca * cb * dcz);
+			dcov[0] = (T.m[0][0] * T.m[0][0] * dL_da + T.m[0][0] * T.m[1][0] * dL_db + T.m[1][0] * T.m[1][0] * dL_dc);
+			dcov[3] = (T.m[0][1] * T.m[0][1] * dL_da + T.m[0][1] * T.m[1][1] * dL_db + T.m[1][1] * T.m[1][1] * dL_dc);
+			dcov[5] = (T.m[0][2] * T.m[0][2] * dL_da + T.m[0][2] * T.m[1][2] * dL_db + T.m[1][2] * T.m[1][2] * dL_dc);
+			dcov[1] = 2 * T.m[0][0] * T.m[0][1] * dL_da + (T.m[0][0] * T.m[1][1] + T.m[0][1] * T.m[1][0]) * dL_db + 2 * T.m[1][0] * T.m[1][1] * dL_dc;
+			dcov[2] = 2 * T.m[0][0] * T.m[0][2] * dL_da + (T.m[0][0] * T.m[1][2] + T.m[0][2] * T.m[1][0]) * dL_db + 2 * T.m[1][0] * T.m[1][2] * dL_dc;
+			dcov[4] = 2 * T.m[0][2] * T.m[0][1] * dL_da + (T.m[0][1] * T.m[1][2] + T.m[0][2] * T.m[1][1]) * dL_db + 2 * T.m[1][1] * T.m[1][2] * dL_dc;
+		}
+#define TV(r_, k_) (T.m[r_][0] * Vrk.m[k_][0] + T.m[r_][1] * Vrk.m[k_][1] + T.m[r_][2] * Vrk.m[k_][2])
+		const float dL_dT00 = 2 * TV(0, 0) * dL_da + TV(1, 0) * dL_db;
+		const float dL_dT01 = 2 * TV(0, 1) * dL_da + TV(1, 1) * dL_db;
+		const float dL_dT02 = 2 * TV(0, 2) * dL_da + TV(1, 2) * dL_db;
+		const float dL_dT10 = 2 * TV(1, 0) * dL_dc + TV(0, 0) * dL_db;
+		const float dL_dT11 = 2 * TV(1, 1) * dL_dc + TV(0, 1) * dL_db;
+		const float dL_dT12 = 2 * TV(1, 2) * dL_dc + TV(0, 2) * dL_db;
+#undef TV
+		const float dL_dJ00 = Wm.m[0][0] * dL_dT00 + Wm.m[0][1] * dL_dT01 + Wm.m[0][2] * dL_dT02;
+		const float dL_dJ02 = Wm.m[2][0] * dL_dT00 + Wm.m[2][1] * dL_dT01 + Wm.m[2][2] * dL_dT02;
+		const float dL_dJ11 = Wm.m[1][0] * dL_dT10 + Wm.m[1][1] * dL_dT11 + Wm.m[1][2] * dL_dT12;
+		const float dL_dJ12 = Wm.m[2][0] * dL_dT10 + Wm.m[2][1] * dL_dT11 + Wm.m[2][2] * dL_dT12;
+		const float tz = 1.f / t.z;
+		const float tz2 = tz * tz;
+		const float tz3 = tz2 * tz;
+		const float dL_dtx = x_grad_mul * -h_x * tz2 * dL_dJ02;
+		const float dL_dty = y_grad_mul * -h_y * tz2 * dL_dJ12;
+		const float dL_dtz = -h_x * tz2 * dL_dJ00 - h_y * tz2 * dL_dJ11 + (2 * h_x * t.x) * tz3 * dL_dJ02 + (2 * h_y * t.y) * tz3 * dL_dJ12;
+		const float* vm = a.viewmatrix;  // transformVec4x3Transpose, auxiliary.h:91-99
+		dmean3D[0] = vm[0] * dL_dtx + vm[1] * dL_dty + vm[2] * dL_dtz;
+		dmean3D[1] = vm[4] * dL_dtx + vm[5] * dL_dty + vm[6] * dL_dtz;
+		dmean3D[2] = vm[8] * dL_dtx + vm[9] * dL_dty + vm[10] * dL_dtz;
+
+		// ---- preprocessCUDA backward, backward.cu:349-399 ----
+		const float* proj = a.projmatrix;
+		const float m_hom_w = proj[3] * mean.x + proj[7] * mean.y + proj[11] * mean.z + proj[15];
+		const float m_w = 1.0f / (m_hom_w + 0.0000001f);
+		const float mul1 = (proj[0] * mean.x + proj[4] * mean.y + proj[8] * mean.z + proj[12]) * m_w * m_w;
+		const float mul2 = (proj[1] * mean.x + proj[5] * mean.y + proj[9] * mean.z + proj[13]) * m_w * m_w;
+		const float gx2 = dmean2D[0], gy2 = dmean2D[1];
+		dmean3D[0] += (proj[0] * m_w - proj[3] * mul1) * gx2 + (proj[1] * m_w - proj[3] * mul2) * gy2;
+		dmean3D[1] += (proj[4] * m_w - proj[7] * mul1) * gx2 + (proj[5] * m_w - proj[7] * mul2) * gy2;
+		dmean3D[2] += (proj[8] * m_w - proj[11] * mul1) * gx2 + (proj[9] * m_w - proj[11] * mul2) * gy2;
+
+		if (a.shs)
+			gsr_sh_backward(a.D, M, mean, a.cam_pos, a.shs + (size_t)idx * M * 3, a.g.clamped[idx], dcolor, dmean3D, dsh);
+		if (a.scales)
+			gsr_cov3d_backward(sc, a.scale_modifier, q, dcov, dscale, drot);
+	}
+
+	if ((!visible || !a.shs) && dsh)
+		for (int k = 0; k < M * 3; k++) dsh[k] = 0.f;
+#pragma unroll
+	for (int k = 0; k < 3; k++) {
+		a.dL_dmean2D[3 * (size_t)idx + k] = dmean2D[k];
+		a.dL_dcolor[3 * (size_t)idx + k] = dcolor[k];
+		a.dL_dmean3D[3 * (size_t)idx + k] = dmean3D[k];
+		a.dL_dscale[3 * (size_t)idx + k] = dscale[k];
+	}
+#pragma unroll
+	for (int k = 0; k < 4; k++) {
+		a.dL_dconic[4 * (size_t)idx + k] = dconic[k];
+		a.dL_drot[4 * (size_t)idx + k] = drot[k];
+	}
+#pragma unroll
+	for (int k = 0; k < 6; k++) a.dL_dcov3D[6 * (size_t)idx + k] = dcov[k];
+	a.dL_dopacity[idx] = dop;
+}
+
+void gsr_launch_gaussian_backward(const GsrGaussianBackwardArgs& a, hipStream_t s)
+{
+	hipLaunchKernelGGL(gsr_gaussian_backward_kernel, dim3((a.P + 255) / 256), dim3(256), 0, s, a);
+}

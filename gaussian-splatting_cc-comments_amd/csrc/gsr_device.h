@@ -1,0 +1,192 @@
+// gsr_device.h -- device-side helpers shared by the gfx950 kernels.
+//
+// Per-Gaussian arithmetic follows the reference expression by expression so that integer
+// outcomes (radii, tile rectangles, keys) are bit-comparable with the CPU oracle; the files
+// that include the "exact" helpers are compiled with -ffp-contract=off.
+// Reference paths are relative to submodules/diff-gaussian-rasterization/.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define GSR_TILE_X 16  // cuda_rasterizer/config.h:16
+#define GSR_TILE_Y 16  // cuda_rasterizer/config.h:17
+#define GSR_TILE_PIX 256
+
+// cuda_rasterizer/auxiliary.h:22-39
+#define GSR_SH_C0 0.28209479177387814f
+#define GSR_SH_C1 0.4886025119029199f
+__device__ static const float GSR_SH_C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
+                                              -1.0925484305920792f, 0.5462742152960396f};
+__device__ static const float GSR_SH_C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f,
+                                              0.3731763325901154f,  -0.4570457994644658f, 1.445305721320277f,
+                                              -0.5900435899266435f};
+
+// One 48-byte record per Gaussian: everything the blend kernels gather per (Gaussian, tile)
+// instance, so a batch load is three 16-byte reads of one contiguous record.
+struct __attribute__((aligned(16))) GsrSplat {
+	float x, y;           // pixel-space mean (forward.cu:294)
+	float ca, cb;         // conic a, b
+	float cc, opacity;    // conic c, opacity (forward.cu:320)
+	float r, g;           // colour
+	float b;
+	uint32_t slot_base;   // first (Gaussian,tile) slot = point_offsets[i] - tiles_touched[i]
+	uint32_t rect_min;    // tile rect min: x | y << 16
+	uint32_t rect_wh;     // tile rect size: w | h << 16
+};
+static_assert(sizeof(GsrSplat) == 48, "splat record must be 48 bytes");
+
+// Per-(Gaussian,tile) gradient record written by the backward blend (12 floats, 9 used).
+struct __attribute__((aligned(16))) GsrGradSlot {
+	float dmx, dmy;       // dL/dmean2D.xy (already scaled by 0.5*W, 0.5*H)
+	float dca, dcb;       // dL/dconic .x .y
+	float dcc, dop;       // dL/dconic .w, dL/dopacity
+	float dr, dg;
+	float db, pad0, pad1, pad2;
+};
+static_assert(sizeof(GsrGradSlot) == 48, "grad slot must be 48 bytes");
+
+struct GsrMat3 { float m[3][3]; };  // m[col][row] as glm
+struct GsrVec3 { float x, y, z; };
+
+// glm operator*(mat3,mat3), third_party/glm/glm/detail/type_mat3x3.inl:486-519
+__device__ __forceinline__ GsrMat3 gsr_mat3_mul(const GsrMat3& a, const GsrMat3& b)
+{
+	GsrMat3 r;
+#pragma unroll
+	for (int c = 0; c < 3; c++)
+#pragma unroll
+		for (int w = 0; w < 3; w++)
+			r.m[c][w] = a.m[0][w] * b.m[c][0] + a.m[1][w] * b.m[c][1] + a.m[2][w] * b.m[c][2];
+	return r;
+}
+
+__device__ __forceinline__ GsrMat3 gsr_mat3_transpose(const GsrMat3& a)
+{
+	GsrMat3 r;
+#pragma unroll
+	for (int c = 0; c < 3; c++)
+#pragma unroll
+		for (int w = 0; w < 3; w++)
+			r.m[c][w] = a.m[w][c];
+	return r;
+}
+
+// float -> int with the device's saturating semantics (NaN -> 0), as cvt.rzi in the reference
+__device__ __forceinline__ int gsr_f2i(float f)
+{
+	if (f != f) return 0;
+	if (f >= 2147483648.0f) return 2147483647;
+	if (f <= -2147483648.0f) return (-2147483647 - 1);
+	return (int)f;
+}
+
+// auxiliary.h:42-45 (double arithmetic)
+__device__ __forceinline__ float gsr_ndc2pix(float v, int S)
+{
+	return (float)(((v + 1.0) * S - 1.0) * 0.5);
+}
+
+// auxiliary.h:48-58
+__device__ __forceinline__ void gsr_get_rect(float px, float py, int max_radius, int gx, int gy, int& minx,
+                                             int& miny, int& maxx, int& maxy)
+{
+	minx = min(gx, max(0, gsr_f2i((px - max_radius) / GSR_TILE_X)));
+	miny = min(gy, max(0, gsr_f2i((py - max_radius) / GSR_TILE_Y)));
+	maxx = min(gx, max(0, gsr_f2i((px + max_radius + GSR_TILE_X - 1) / GSR_TILE_X)));
+	maxy = min(gy, max(0, gsr_f2i((py + max_radius + GSR_TILE_Y - 1) / GSR_TILE_Y)));
+}
+
+// auxiliary.h:60-69
+__device__ __forceinline__ GsrVec3 gsr_transform_point_4x3(const GsrVec3& p, const float* m)
+{
+	GsrVec3 r = {m[0] * p.x + m[4] * p.y + m[8] * p.z + m[12], m[1] * p.x + m[5] * p.y + m[9] * p.z + m[13],
+	             m[2] * p.x + m[6] * p.y + m[10] * p.z + m[14]};
+	return r;
+}
+
+// forward.cu:146-180 rotation part (quaternion used unnormalised)
+__device__ __forceinline__ GsrMat3 gsr_build_R(float r, float x, float y, float z)
+{
+	GsrMat3 R;
+	R.m[0][0] = 1.f - 2.f * (y * y + z * z); R.m[0][1] = 2.f * (x * y - r * z); R.m[0][2] = 2.f * (x * z + r * y);
+	R.m[1][0] = 2.f * (x * y + r * z); R.m[1][1] = 1.f - 2.f * (x * x + z * z); R.m[1][2] = 2.f * (y * z - r * x);
+	R.m[2][0] = 2.f * (x * z - r * y); R.m[2][1] = 2.f * (y * z + r * x); R.m[2][2] = 1.f - 2.f * (x * x + y * y);
+	return R;
+}
+
+__device__ __forceinline__ GsrMat3 gsr_diag3(float a, float b, float c)
+{
+	GsrMat3 S;
+#pragma unroll
+	for (int i = 0; i < 3; i++)
+#pragma unroll
+		for (int j = 0; j < 3; j++) S.m[i][j] = 0.f;
+	S.m[0][0] = a; S.m[1][1] = b; S.m[2][2] = c;
+	return S;
+}
+
+// forward.cu:146-180 computeCov3D
+__device__ __forceinline__ void gsr_cov3d(const float* scale, float mod, const float* q, float* cov3D)
+{
+	GsrMat3 S = gsr_diag3(mod * scale[0], mod * scale[1], mod * scale[2]);
+	GsrMat3 R = gsr_build_R(q[0], q[1], q[2], q[3]);
+	GsrMat3 M = gsr_mat3_mul(S, R);
+	GsrMat3 Sigma = gsr_mat3_mul(gsr_mat3_transpose(M), M);
+	cov3D[0] = Sigma.m[0][0]; cov3D[1] = Sigma.m[0][1]; cov3D[2] = Sigma.m[0][2];
+	cov3D[3] = Sigma.m[1][1]; cov3D[4] = Sigma.m[1][2]; cov3D[5] = Sigma.m[2][2];
+}
+
+// forward.cu:84-140 computeCov2D, also recomputed by backward.cu:144-199
+struct GsrCov2D {
+	GsrMat3 T, W, Vrk;
+	GsrVec3 t;
+	float txtz, tytz, limx, limy;
+	float a, b, c;
+};
+
+__device__ __forceinline__ void gsr_cov2d(const GsrVec3& mean, float focal_x, float focal_y, float tan_fovx,
+                                          float tan_fovy, const float* cov3D, const float* vm, GsrCov2D& o)
+{
+	GsrVec3 t = gsr_transform_point_4x3(mean, vm);
+	o.limx = 1.3f * tan_fovx;
+	o.limy = 1.3f * tan_fovy;
+	o.txtz = t.x / t.z;
+	o.tytz = t.y / t.z;
+	t.x = fminf(o.limx, fmaxf(-o.limx, o.txtz)) * t.z;
+	t.y = fminf(o.limy, fmaxf(-o.limy, o.tytz)) * t.z;
+	o.t = t;
+	GsrMat3 J;
+	J.m[0][0] = focal_x / t.z; J.m[0][1] = 0.0f; J.m[0][2] = -(focal_x * t.x) / (t.z * t.z);
+	J.m[1][0] = 0.0f; J.m[1][1] = focal_y / t.z; J.m[1][2] = -(focal_y * t.y) / (t.z * t.z);
+	J.m[2][0] = 0.f; J.m[2][1] = 0.f; J.m[2][2] = 0.f;
+	o.W.m[0][0] = vm[0]; o.W.m[0][1] = vm[4]; o.W.m[0][2] = vm[8];
+	o.W.m[1][0] = vm[1]; o.W.m[1][1] = vm[5]; o.W.m[1][2] = vm[9];
+	o.W.m[2][0] = vm[2]; o.W.m[2][1] = vm[6]; o.W.m[2][2] = vm[10];
+	o.T = gsr_mat3_mul(o.W, J);
+	o.Vrk.m[0][0] = cov3D[0]; o.Vrk.m[0][1] = cov3D[1]; o.Vrk.m[0][2] = cov3D[2];
+	o.Vrk.m[1][0] = cov3D[1]; o.Vrk.m[1][1] = cov3D[3]; o.Vrk.m[1][2] = cov3D[4];
+	o.Vrk.m[2][0] = cov3D[2]; o.Vrk.m[2][1] = cov3D[4]; o.Vrk.m[2][2] = cov3D[5];
+	GsrMat3 cov = gsr_mat3_mul(gsr_mat3_mul(gsr_mat3_transpose(o.T), gsr_mat3_transpose(o.Vrk)), o.T);
+	o.a = cov.m[0][0] + 0.3f;
+	o.b = cov.m[0][1];
+	o.c = cov.m[1][1] + 0.3f;
+}
+
+// ---- wave64 cross-lane helpers (DPP) -------------------------------------------------------
+template <int CTRL, int ROW_MASK, int BANK_MASK, bool BOUND>
+__device__ __forceinline__ float gsr_dpp_mov(float v)
+{
+	return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, BANK_MASK, BOUND));
+}
+
+// Sum over the 64 lanes of a wave; the total is valid in lane 63 (other lanes hold partials).
+__device__ __forceinline__ float gsr_wave_sum_to_lane63(float v)
+{
+	v += gsr_dpp_mov<0xB1, 0xF, 0xF, true>(v);   // quad_perm [1,0,3,2]
+	v += gsr_dpp_mov<0x4E, 0xF, 0xF, true>(v);   // quad_perm [2,3,0,1]
+	v += gsr_dpp_mov<0x141, 0xF, 0xF, true>(v);  // row_half_mirror
+	v += gsr_dpp_mov<0x140, 0xF, 0xF, true>(v);  // row_mirror  -> every lane holds its row's sum
+	v += gsr_dpp_mov<0x142, 0xA, 0xF, false>(v); // row_bcast:15 into rows 1,3
+	v += gsr_dpp_mov<0x143, 0xC, 0xF, false>(v); // row_bcast:31 into rows 2,3 -> lane 63 = total
+	return v;
+}

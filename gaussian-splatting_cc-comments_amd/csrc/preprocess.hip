@@ -1,0 +1,149 @@
+// preprocess.hip -- per-Gaussian forward stage (compiled with -ffp-contract=off).
+//
+// Replaces preprocessCUDA (cuda_rasterizer/forward.cu:192-324) and checkFrustum
+// (cuda_rasterizer/rasterizer_impl.cu:56-69).  One Gaussian per lane, 256-thread workgroups.
+// Outputs go into one 48-byte splat record per Gaussian instead of five separate arrays, and the
+// kernel also emits the per-workgroup sum of tiles_touched so the prefix sum that follows needs
+// no extra pass over P.
+#include "gsr_internal.h"
+
+// forward.cu:21-81 computeColorFromSH, one channel at a time in the glm::vec3 expression order
+__device__ __forceinline__ float gsr_sh_channel(int deg, const float* sh, int ch, float x, float y, float z)
+{
+#define SH(k) sh[(k) * 3 + ch]
+	float result = GSR_SH_C0 * SH(0);
+	if (deg > 0) {
+		result = result - GSR_SH_C1 * y * SH(1) + GSR_SH_C1 * z * SH(2) - GSR_SH_C1 * x * SH(3);
+		if (deg > 1) {
+			float xx = x * x, yy = y * y, zz = z * z;
+			float xy = x * y, yz = y * z, xz = x * z;
+			result = result + GSR_SH_C2[0] * xy * SH(4) + GSR_SH_C2[1] * yz * SH(5) +
+			         GSR_SH_C2[2] * (2.0f * zz - xx - yy) * SH(6) + GSR_SH_C2[3] * xz * SH(7) +
+			         GSR_SH_C2[4] * (xx - yy) * SH(8);
+			if (deg > 2) {
+				result = result + GSR_SH_C3[0] * y * (3.0f * xx - yy) * SH(9) + GSR_SH_C3[1] * xy * z * SH(10) +
+				         GSR_SH_C3[2] * y * (4.0f * zz - xx - yy) * SH(11) +
+				         GSR_SH_C3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy) * SH(12) +
+				         GSR_SH_C3[4] * x * (4.0f * zz - xx - yy) * SH(13) + GSR_SH_C3[5] * z * (xx - yy) * SH(14) +
+				         GSR_SH_C3[6] * x * (xx - 3.0f * yy) * SH(15);
+			}
+		}
+	}
+#undef SH
+	return result + 0.5f;
+}
+
+__global__ void __launch_bounds__(GSR_PREPROCESS_BLOCK) gsr_preprocess_kernel(GsrPreprocessArgs a)
+{
+	const int idx = blockIdx.x * GSR_PREPROCESS_BLOCK + threadIdx.x;
+	uint32_t tiles = 0;
+	int radius_out = 0;
+	const int gx = (a.W + GSR_TILE_X - 1) / GSR_TILE_X, gy = (a.H + GSR_TILE_Y - 1) / GSR_TILE_Y;
+
+	if (idx < a.P) {
+		do {
+			GsrVec3 p_orig = {a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]};
+			// in_frustum, auxiliary.h:144-175
+			GsrVec3 p_view = gsr_transform_point_4x3(p_orig, a.viewmatrix);
+			if (p_view.z <= 0.2f) {
+				if (a.prefiltered) atomicOr(&a.g.status[0], 1u);
+				break;
+			}
+			const float* pm = a.projmatrix;
+			float hx = pm[0] * p_orig.x + pm[4] * p_orig.y + pm[8] * p_orig.z + pm[12];
+			float hy = pm[1] * p_orig.x + pm[5] * p_orig.y + pm[9] * p_orig.z + pm[13];
+			float hw = pm[3] * p_orig.x + pm[7] * p_orig.y + pm[11] * p_orig.z + pm[15];
+			float p_w = 1.0f / (hw + 0.0000001f);
+			float p_proj_x = hx * p_w, p_proj_y = hy * p_w;
+
+			float cov3D[6];
+			if (a.cov3D_precomp) {
+#pragma unroll
+				for (int k = 0; k < 6; k++) cov3D[k] = a.cov3D_precomp[6 * (size_t)idx + k];
+			} else {
+				float sc[3] = {a.scales[3 * idx], a.scales[3 * idx + 1], a.scales[3 * idx + 2]};
+				float q[4] = {a.rotations[4 * idx], a.rotations[4 * idx + 1], a.rotations[4 * idx + 2], a.rotations[4 * idx + 3]};
+				gsr_cov3d(sc, a.scale_modifier, q, cov3D);
+			}
+			GsrCov2D c2;
+			gsr_cov2d(p_orig, a.focal_x, a.focal_y, a.tan_fovx, a.tan_fovy, cov3D, a.viewmatrix, c2);
+			const float cx = c2.a, cy = c2.b, cz = c2.c;
+			float det = (cx * cz - cy * cy);
+			if (det == 0.0f) break;
+			float det_inv = 1.f / det;
+			float conic_a = cz * det_inv, conic_b = -cy * det_inv, conic_c = cx * det_inv;
+			float mid = 0.5f * (cx + cz);
+			float lambda1 = mid + sqrtf(fmaxf(0.1f, mid * mid - det));
+			float lambda2 = mid - sqrtf(fmaxf(0.1f, mid * mid - det));
+			float my_radius = ceilf(3.f * sqrtf(fmaxf(lambda1, lambda2)));
+			float pix = gsr_ndc2pix(p_proj_x, a.W), piy = gsr_ndc2pix(p_proj_y, a.H);
+			int minx, miny, maxx, maxy;
+			gsr_get_rect(pix, piy, gsr_f2i(my_radius), gx, gy, minx, miny, maxx, maxy);
+			if ((maxx - minx) * (maxy - miny) == 0) break;
+
+			float rgb[3];
+			uint8_t clamp_bits = 0;
+			if (a.colors_precomp) {
+				rgb[0] = a.colors_precomp[3 * idx]; rgb[1] = a.colors_precomp[3 * idx + 1]; rgb[2] = a.colors_precomp[3 * idx + 2];
+			} else {
+				float dx = p_orig.x - a.cam_pos[0], dy = p_orig.y - a.cam_pos[1], dz = p_orig.z - a.cam_pos[2];
+				float len = sqrtf(dx * dx + dy * dy + dz * dz);
+				dx = dx / len; dy = dy / len; dz = dz / len;
+				const float* sh = a.shs + (size_t)idx * a.M * 3;
+#pragma unroll
+				for (int ch = 0; ch < 3; ch++) {
+					float v = gsr_sh_channel(a.D, sh, ch, dx, dy, dz);
+					if (v < 0) clamp_bits |= (uint8_t)(1u << ch);
+					rgb[ch] = fmaxf(v, 0.0f);
+				}
+			}
+			tiles = (uint32_t)((maxy - miny) * (maxx - minx));
+			radius_out = gsr_f2i(my_radius);
+			a.g.depths[idx] = p_view.z;
+			a.g.clamped[idx] = clamp_bits;
+			float4* rec = reinterpret_cast<float4*>(a.g.splat + idx);
+			rec[0] = make_float4(pix, piy, conic_a, conic_b);
+			rec[1] = make_float4(conic_c, a.opacities[idx], rgb[0], rgb[1]);
+			rec[2] = make_float4(rgb[2], 0.f /* slot_base: filled after the scan */,
+			                     __uint_as_float((uint32_t)minx | ((uint32_t)miny << 16)),
+			                     __uint_as_float((uint32_t)(maxx - minx) | ((uint32_t)(maxy - miny) << 16)));
+		} while (0);
+		a.radii[idx] = radius_out;
+		a.g.tiles_touched[idx] = tiles;
+	}
+
+	// workgroup sum of tiles_touched -> block_sums[blockIdx.x]
+	__shared__ uint32_t wsum[GSR_PREPROCESS_BLOCK / 64];
+	uint32_t v = tiles;
+#pragma unroll
+	for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+	if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = v;
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		uint32_t t = 0;
+#pragma unroll
+		for (int w = 0; w < GSR_PREPROCESS_BLOCK / 64; w++) t += wsum[w];
+		a.g.block_sums[blockIdx.x] = t;
+	}
+}
+
+void gsr_launch_preprocess(const GsrPreprocessArgs& a, hipStream_t s)
+{
+	const int nb = (a.P + GSR_PREPROCESS_BLOCK - 1) / GSR_PREPROCESS_BLOCK;
+	hipLaunchKernelGGL(gsr_preprocess_kernel, dim3(nb), dim3(GSR_PREPROCESS_BLOCK), 0, s, a);
+}
+
+// rasterizer_impl.cu:56-69 checkFrustum: only the view-space z test of in_frustum survives
+__global__ void gsr_mark_visible_kernel(int P, const float* means3D, const float* viewmatrix, uint8_t* present)
+{
+	const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+	if (idx >= P) return;
+	GsrVec3 p = {means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]};
+	GsrVec3 pv = gsr_transform_point_4x3(p, viewmatrix);
+	present[idx] = !(pv.z <= 0.2f);
+}
+
+void gsr_launch_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8_t* present, hipStream_t s)
+{
+	hipLaunchKernelGGL(gsr_mark_visible_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, means3D, viewmatrix, present);
+}

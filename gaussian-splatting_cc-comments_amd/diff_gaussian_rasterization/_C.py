@@ -1,0 +1,244 @@
+"""ctypes binding of libgsr_hip.so with the surface of the reference's torch extension
+`diff_gaussian_rasterization._C` (submodules/diff-gaussian-rasterization/ext.cpp:18-22):
+
+    rasterize_gaussians(...)          -> rasterize_points.cu:38-130  RasterizeGaussiansCUDA
+    rasterize_gaussians_backward(...) -> rasterize_points.cu:132-216 RasterizeGaussiansBackwardCUDA
+    mark_visible(...)                 -> rasterize_points.cu:218-237 markVisible
+
+Same positional arguments, same return tuples.  PyTorch is only the allocator and the stream
+provider here: every tensor is handed to the C ABI (include/gsr.h) as a raw device pointer.
+There is no CPU fallback: a missing library or a non-HIP tensor raises.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(os.path.dirname(_HERE), "libgsr_hip.so")
+_lib = None
+
+_vp = ctypes.c_void_p
+_i = ctypes.c_int
+_i64 = ctypes.c_int64
+_f = ctypes.c_float
+_sz = ctypes.c_size_t
+
+
+class GeometryLayout(ctypes.Structure):
+    _fields_ = [(n, _sz) for n in ("splat", "depths", "tiles_touched", "point_offsets", "clamped", "status",
+                                   "scan_temp", "total")]
+
+
+class ImageLayout(ctypes.Structure):
+    _fields_ = [(n, _sz) for n in ("final_T", "n_contrib", "ranges", "tile_max_contrib", "total")]
+
+
+class BinningLayout(ctypes.Structure):
+    _fields_ = [(n, _sz) for n in ("point_list", "point_list_unsorted", "keys", "keys_unsorted", "sort_temp",
+                                   "sort_temp_bytes", "total")]
+
+
+class KernelTime(ctypes.Structure):
+    _fields_ = [("name", ctypes.c_char_p), ("ms", _f)]
+
+
+def library_path():
+    return _LIB_PATH
+
+
+def lib():
+    """Load libgsr_hip.so (once).  Fails loudly when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise RuntimeError(
+            f"{_LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the rasterizer.")
+    L = ctypes.CDLL(_LIB_PATH)
+    L.gsr_last_error.restype = ctypes.c_char_p
+    L.gsr_version.restype = ctypes.c_char_p
+    L.gsr_geometry_bytes.restype = _sz
+    L.gsr_geometry_bytes.argtypes = [_i]
+    L.gsr_image_bytes.restype = _sz
+    L.gsr_image_bytes.argtypes = [_i, _i]
+    L.gsr_binning_bytes.restype = _sz
+    L.gsr_binning_bytes.argtypes = [_i, _i64, _i, _i]
+    L.gsr_backward_scratch_bytes.restype = _sz
+    L.gsr_backward_scratch_bytes.argtypes = [_i, _i64]
+    L.gsr_geometry_layout_of.argtypes = [_i, ctypes.POINTER(GeometryLayout)]
+    L.gsr_image_layout_of.argtypes = [_i, _i, ctypes.POINTER(ImageLayout)]
+    L.gsr_binning_layout_of.argtypes = [_i, _i64, _i, _i, ctypes.POINTER(BinningLayout)]
+    L.gsr_get_higher_msb.restype = ctypes.c_uint32
+    L.gsr_get_higher_msb.argtypes = [ctypes.c_uint32]
+    L.gsr_forward_preprocess.restype = _i
+    L.gsr_forward_preprocess.argtypes = [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp,
+                                         _f, _f, _i, _vp, _vp, ctypes.POINTER(_i64), _vp, _i]
+    L.gsr_forward_render.restype = _i
+    L.gsr_forward_render.argtypes = [_i, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i]
+    L.gsr_backward.restype = _i
+    L.gsr_backward.argtypes = [_i, _i, _i, _i64, _i, _i] + [_vp] * 5 + [_f] + [_vp] * 5 + [_f, _f] + [_vp] * 16 + [_i]
+    L.gsr_mark_visible.restype = _i
+    L.gsr_mark_visible.argtypes = [_i, _vp, _vp, _vp, _vp, _vp]
+    L.gsr_profile_begin.restype = _i
+    L.gsr_profile_end.restype = _i
+    L.gsr_profile_end.argtypes = [ctypes.POINTER(KernelTime), _i]
+    _lib = L
+    return L
+
+
+def _check(rc):
+    if rc != 0:
+        raise RuntimeError(f"gsr error {rc}: {lib().gsr_last_error().decode()}")
+
+
+def _ptr(t):
+    """Raw device pointer; an empty tensor is the reference's "not provided" and becomes NULL
+    (rasterize_points.cu:108-125)."""
+    if t is None or t.numel() == 0:
+        return None
+    return t.data_ptr()
+
+
+def _dev_f32(t, device, what):
+    if t.numel() == 0:
+        return t
+    if t.device != device:
+        raise RuntimeError(f"{what} must be on {device} (got {t.device}); the HIP rasterizer has no CPU path")
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"{what} must be float32 (got {t.dtype})")
+    return t.contiguous()
+
+
+def _stream(device):
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
+                        viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos,
+                        prefiltered, debug):
+    """-> (num_rendered, out_color (3,H,W) f32, radii (P,) i32, geomBuffer, binningBuffer, imgBuffer)"""
+    if means3D.ndimension() != 2 or means3D.size(1) != 3:
+        raise RuntimeError("means3D must have dimensions (num_points, 3)")  # rasterize_points.cu:60-63
+    if not means3D.is_cuda:
+        raise RuntimeError("means3D must be a HIP (cuda) tensor; the HIP rasterizer has no CPU path")
+    L = lib()
+    dev = means3D.device
+    P, H, W = int(means3D.size(0)), int(image_height), int(image_width)
+    means3D = _dev_f32(means3D, dev, "means3D")
+    background = _dev_f32(background, dev, "bg")
+    colors, opacity, scales, rotations, cov3D_precomp, sh = (
+        _dev_f32(t, dev, n) for t, n in ((colors, "colors_precomp"), (opacity, "opacities"), (scales, "scales"),
+                                         (rotations, "rotations"), (cov3D_precomp, "cov3D_precomp"), (sh, "shs")))
+    viewmatrix, projmatrix, campos = (_dev_f32(t, dev, n) for t, n in ((viewmatrix, "viewmatrix"),
+                                                                        (projmatrix, "projmatrix"), (campos, "campos")))
+    byte = dict(dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        out_color = torch.zeros((3, H, W), dtype=torch.float32, device=dev) if P == 0 else \
+            torch.empty((3, H, W), dtype=torch.float32, device=dev)
+        radii = torch.empty((P,), dtype=torch.int32, device=dev)
+        if P == 0:  # rasterize_points.cu:94
+            e = torch.empty((0,), **byte)
+            return 0, out_color, radii, e, e.clone(), e.clone()
+        M = int(sh.size(1)) if sh.numel() != 0 else 0
+        geom = torch.empty((L.gsr_geometry_bytes(P),), **byte)
+        img = torch.empty((L.gsr_image_bytes(W, H),), **byte)
+        R = _i64(0)
+        stream = _stream(dev)
+        _check(L.gsr_forward_preprocess(P, int(degree), M, W, H, _ptr(means3D), _ptr(sh), _ptr(colors), _ptr(opacity),
+                                        _ptr(scales), float(scale_modifier), _ptr(rotations), _ptr(cov3D_precomp),
+                                        _ptr(viewmatrix), _ptr(projmatrix), _ptr(campos), float(tan_fovx),
+                                        float(tan_fovy), int(bool(prefiltered)), _ptr(radii), _ptr(geom),
+                                        ctypes.byref(R), stream, int(bool(debug))))
+        R = int(R.value)
+        binning = torch.empty((L.gsr_binning_bytes(P, R, W, H),), **byte)
+        _check(L.gsr_forward_render(P, R, W, H, _ptr(background), _ptr(radii), _ptr(geom), _ptr(binning), _ptr(img),
+                                    _ptr(out_color), stream, int(bool(debug))))
+    return R, out_color, radii, geom, binning, img
+
+
+def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier,
+                                 cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, sh, degree,
+                                 campos, geomBuffer, R, binningBuffer, imageBuffer, debug):
+    """-> (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations)"""
+    L = lib()
+    dev = means3D.device
+    P = int(means3D.size(0))
+    H, W = int(dL_dout_color.size(1)), int(dL_dout_color.size(2))
+    M = int(sh.size(1)) if sh.numel() != 0 else 0
+    f32 = dict(dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        # every element is written by gsr_backward (no zero-fill pass, unlike rasterize_points.cu:168-178)
+        alloc = torch.zeros if P == 0 else torch.empty
+        dL_dmeans3D = alloc((P, 3), **f32)
+        dL_dmeans2D = alloc((P, 3), **f32)
+        dL_dcolors = alloc((P, 3), **f32)
+        dL_dconic = alloc((P, 2, 2), **f32)
+        dL_dopacity = alloc((P, 1), **f32)
+        dL_dcov3D = alloc((P, 6), **f32)
+        dL_dsh = alloc((P, M, 3), **f32)
+        dL_dscales = alloc((P, 3), **f32)
+        dL_drotations = alloc((P, 4), **f32)
+        if P != 0:
+            means3D = _dev_f32(means3D, dev, "means3D")
+            dL_dout_color = _dev_f32(dL_dout_color, dev, "dL_dout_color")
+            background, colors, scales, rotations, cov3D_precomp, sh, viewmatrix, projmatrix, campos = (
+                _dev_f32(t, dev, "input") for t in (background, colors, scales, rotations, cov3D_precomp, sh, viewmatrix,
+                                                    projmatrix, campos))
+            scratch = torch.empty((L.gsr_backward_scratch_bytes(P, int(R)),), dtype=torch.uint8, device=dev)
+            _check(L.gsr_backward(P, int(degree), M, int(R), W, H, _ptr(background), _ptr(means3D), _ptr(sh), _ptr(colors),
+                                  _ptr(scales), float(scale_modifier), _ptr(rotations), _ptr(cov3D_precomp),
+                                  _ptr(viewmatrix), _ptr(projmatrix), _ptr(campos), float(tan_fovx), float(tan_fovy),
+                                  _ptr(radii), _ptr(geomBuffer), _ptr(binningBuffer), _ptr(imageBuffer), _ptr(scratch),
+                                  _ptr(dL_dout_color), _ptr(dL_dmeans2D), _ptr(dL_dconic), _ptr(dL_dopacity),
+                                  _ptr(dL_dcolors), _ptr(dL_dmeans3D), _ptr(dL_dcov3D), _ptr(dL_dsh), _ptr(dL_dscales),
+                                  _ptr(dL_drotations), _stream(dev), int(bool(debug))))
+            scratch.record_stream(torch.cuda.current_stream(dev))
+    return dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations
+
+
+def mark_visible(means3D, viewmatrix, projmatrix):
+    """-> bool (P,)"""
+    if not means3D.is_cuda:
+        raise RuntimeError("means3D must be a HIP (cuda) tensor; the HIP rasterizer has no CPU path")
+    L = lib()
+    dev = means3D.device
+    P = int(means3D.size(0))
+    present = torch.zeros((P,), dtype=torch.bool, device=dev)
+    if P != 0:
+        means3D = _dev_f32(means3D, dev, "means3D")
+        viewmatrix = _dev_f32(viewmatrix, dev, "viewmatrix")
+        projmatrix = _dev_f32(projmatrix, dev, "projmatrix")
+        with torch.cuda.device(dev):
+            _check(L.gsr_mark_visible(P, _ptr(means3D), _ptr(viewmatrix), _ptr(projmatrix), _ptr(present), _stream(dev)))
+    return present
+
+
+# ---- introspection helpers (tests / bench; not part of the reference surface) ----------------------
+def geometry_layout(P):
+    o = GeometryLayout()
+    _check(lib().gsr_geometry_layout_of(P, ctypes.byref(o)))
+    return o
+
+
+def image_layout(W, H):
+    o = ImageLayout()
+    _check(lib().gsr_image_layout_of(W, H, ctypes.byref(o)))
+    return o
+
+
+def binning_layout(P, R, W, H):
+    o = BinningLayout()
+    _check(lib().gsr_binning_layout_of(P, R, W, H, ctypes.byref(o)))
+    return o
+
+
+def profile_begin():
+    lib().gsr_profile_begin()
+
+
+def profile_end(capacity=256):
+    arr = (KernelTime * capacity)()
+    n = lib().gsr_profile_end(arr, capacity)
+    return [(arr[k].name.decode(), float(arr[k].ms)) for k in range(n)]

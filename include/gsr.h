@@ -1,0 +1,193 @@
+/*
+ * gsr.h -- C ABI of the MI355X (gfx950) differentiable Gaussian rasterizer, libgsr_hip.so.
+ *
+ * This is the drop-in boundary for the reference's torch extension
+ * `diff_gaussian_rasterization._C` (submodules/diff-gaussian-rasterization/ext.cpp:18-22).
+ * Every entry point takes plain device/host pointers and sizes; the library allocates nothing
+ * on the device, keeps no state between calls and borrows pointers only for the duration of a
+ * call.  All device work is enqueued on the caller's `stream` (a hipStream_t passed as void*).
+ * Pointers are DEVICE pointers unless the parameter name ends in `_host`.
+ *
+ * "Not provided" convention (rasterize_points.cu:108-125): pass NULL for shs / colors_precomp /
+ * scales / rotations / cov3D_precomp exactly where the reference passes an empty tensor.
+ *
+ * Return value: 0 on success, otherwise a negative gsr_status; gsr_last_error() returns a
+ * thread-local message for the last failure.  With debug != 0 every stage is followed by a
+ * stream synchronise + error check, like CHECK_CUDA (cuda_rasterizer/auxiliary.h:177-184).
+ *
+ * The three state buffers (geometry / binning / image) are opaque byte blobs that only travel
+ * forward -> backward, like the reference's geomBuffer / binningBuffer / imgBuffer
+ * (rasterize_points.cu:82-91).  Their layout is this library's own; gsr_*_layout() publishes the
+ * byte offsets so tests can inspect intermediates without extra kernels.
+ */
+#ifndef GSR_H_INCLUDED
+#define GSR_H_INCLUDED
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+	GSR_OK = 0,
+	GSR_ERR_INVALID_ARGUMENT = -1,
+	GSR_ERR_HIP = -2,          /* a HIP runtime call or kernel failed */
+	GSR_ERR_PREFILTERED = -3,  /* prefiltered=1 but a point was culled (auxiliary.h:167-171 __trap) */
+	GSR_ERR_BUFFER_TOO_SMALL = -4
+} gsr_status;
+
+/* Message of the last failing call on this thread ("" if none). */
+const char* gsr_last_error(void);
+
+/* Library / build identification, e.g. "gsr-hip gfx950 r1". */
+const char* gsr_version(void);
+
+/* ---- buffer sizing (replaces required<GeometryState/ImageState/BinningState>(),
+ *      cuda_rasterizer/rasterizer_impl.h:65-73 and the resize callbacks rasterize_points.cu:28-36) */
+size_t gsr_geometry_bytes(int P);
+size_t gsr_image_bytes(int width, int height);
+size_t gsr_binning_bytes(int P, int64_t num_rendered, int width, int height);
+/* Scratch for one gsr_backward() call: [R] 48-byte per-(Gaussian,tile) gradient records written
+ * by the backward blend + [R] validity bytes.  Not kept after the call. */
+size_t gsr_backward_scratch_bytes(int P, int64_t num_rendered);
+
+/* Byte offsets of the typed arrays inside each blob (introspection for tests / debuggers). */
+typedef struct {
+	size_t splat;          /* [P] 48-byte records: xy(2f) conic+opacity(4f) rgb(3f) slot_base(u32) rect_min(u16x2) rect_w(u32) */
+	size_t depths;         /* [P] f32 view-space z */
+	size_t tiles_touched;  /* [P] u32 */
+	size_t point_offsets;  /* [P] u32 inclusive prefix sum of tiles_touched */
+	size_t clamped;        /* [P] u8 bit c set = colour channel c was clamped at 0 */
+	size_t status;         /* [4] u32 device status words (word 0: prefiltered trap) */
+	size_t scan_temp;      /* prefix-sum temp storage */
+	size_t total;
+} gsr_geometry_layout;
+
+typedef struct {
+	size_t final_T;        /* [W*H] f32 */
+	size_t n_contrib;      /* [W*H] u32 */
+	size_t ranges;         /* [tiles] uint2 */
+	size_t tile_max_contrib; /* [tiles] u32 = max n_contrib over the tile's pixels */
+	size_t total;
+} gsr_image_layout;
+
+typedef struct {
+	size_t point_list;          /* [R] u32 sorted Gaussian ids */
+	size_t point_list_unsorted; /* [R] u32 */
+	size_t keys;                /* [R] u64 sorted tile|depth keys */
+	size_t keys_unsorted;       /* [R] u64 */
+	size_t sort_temp;
+	size_t sort_temp_bytes;
+	size_t total;
+} gsr_binning_layout;
+
+int gsr_geometry_layout_of(int P, gsr_geometry_layout* out);
+int gsr_image_layout_of(int width, int height, gsr_image_layout* out);
+int gsr_binning_layout_of(int P, int64_t num_rendered, int width, int height, gsr_binning_layout* out);
+
+/*
+ * Forward, stage 1 of 2: per-Gaussian preprocess + tile-count prefix sum + read-back of the
+ * instance count.  Replaces the first half of CudaRasterizer::Rasterizer::forward
+ * (cuda_rasterizer/rasterizer_impl.cu:227-331: FORWARD::preprocess, cub InclusiveSum, the blocking
+ * cudaMemcpy of num_rendered).  Blocks until `*num_rendered_host` is valid.
+ *   radii [P] int32 out (0 for culled Gaussians); geometry: gsr_geometry_bytes(P) bytes.
+ */
+int gsr_forward_preprocess(
+	int P, int D, int M,
+	int width, int height,
+	const float* means3D,        /* [P][3] */
+	const float* shs,            /* [P][M][3] or NULL */
+	const float* colors_precomp, /* [P][3] or NULL */
+	const float* opacities,      /* [P] */
+	const float* scales,         /* [P][3] or NULL */
+	float scale_modifier,
+	const float* rotations,      /* [P][4] or NULL */
+	const float* cov3D_precomp,  /* [P][6] or NULL */
+	const float* viewmatrix,     /* [16] */
+	const float* projmatrix,     /* [16] */
+	const float* cam_pos,        /* [3] */
+	float tan_fovx, float tan_fovy,
+	int prefiltered,
+	int* radii,
+	void* geometry,
+	int64_t* num_rendered_host,
+	void* stream, int debug);
+
+/*
+ * Forward, stage 2 of 2: key duplication, tile|depth sort, tile ranges, per-tile blend.
+ * Replaces rasterizer_impl.cu:333-410 (duplicateWithKeys, cub SortPairs on bits [0,32+bit),
+ * identifyTileRanges, FORWARD::render).  binning: gsr_binning_bytes(P, num_rendered, w, h) bytes;
+ * image: gsr_image_bytes(w, h) bytes; out_color [3][H][W] fully written (background where empty).
+ */
+int gsr_forward_render(
+	int P, int64_t num_rendered,
+	int width, int height,
+	const float* background,     /* [3] */
+	const int* radii,
+	void* geometry, void* binning, void* image,
+	float* out_color,
+	void* stream, int debug);
+
+/*
+ * Backward.  Replaces CudaRasterizer::Rasterizer::backward (rasterizer_impl.cu:416-518:
+ * BACKWARD::render, computeCov2DCUDA, BACKWARD::preprocess) and the zero-initialised gradient
+ * tensors of rasterize_points.cu:168-178: every element of the eight outputs is written by this
+ * call (zeros for culled Gaussians), so the caller may pass uninitialised memory.
+ *   dL_dpix [3][H][W]; outputs: dL_dmean2D [P][3], dL_dconic [P][4] (the reference's (P,2,2)),
+ *   dL_dopacity [P], dL_dcolor [P][3], dL_dmean3D [P][3], dL_dcov3D [P][6], dL_dsh [P][M][3]
+ *   (may be NULL when M == 0), dL_dscale [P][3], dL_drot [P][4].
+ */
+int gsr_backward(
+	int P, int D, int M, int64_t num_rendered,
+	int width, int height,
+	const float* background,
+	const float* means3D,
+	const float* shs,
+	const float* colors_precomp,
+	const float* scales,
+	float scale_modifier,
+	const float* rotations,
+	const float* cov3D_precomp,
+	const float* viewmatrix,
+	const float* projmatrix,
+	const float* cam_pos,
+	float tan_fovx, float tan_fovy,
+	const int* radii,
+	void* geometry, void* binning, void* image,
+	void* scratch,               /* gsr_backward_scratch_bytes(P, num_rendered) bytes */
+	const float* dL_dpix,
+	float* dL_dmean2D,
+	float* dL_dconic,
+	float* dL_dopacity,
+	float* dL_dcolor,
+	float* dL_dmean3D,
+	float* dL_dcov3D,
+	float* dL_dsh,
+	float* dL_dscale,
+	float* dL_drot,
+	void* stream, int debug);
+
+/* Replaces CudaRasterizer::Rasterizer::markVisible (rasterizer_impl.cu:162-174):
+ * present[i] = 1 iff the view-space z of means3D[i] is > 0.2. */
+int gsr_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,
+                     uint8_t* present, void* stream);
+
+/* rasterizer_impl.cu:37-52 (host helper; exported for tests). */
+uint32_t gsr_get_higher_msb(uint32_t n);
+
+/*
+ * Per-kernel timing hook for benchmarks: when `events_out` is non-NULL in gsr_profile_begin(),
+ * the next forward/backward calls on this thread record HIP events around each kernel on the
+ * caller's stream; gsr_profile_end() synchronises and returns (name, milliseconds) pairs.
+ * Not part of the reference surface.
+ */
+typedef struct { const char* name; float ms; } gsr_kernel_time;
+int gsr_profile_begin(void);
+int gsr_profile_end(gsr_kernel_time* out, int capacity);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GSR_H_INCLUDED */

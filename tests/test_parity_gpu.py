@@ -1,0 +1,199 @@
+"""GPU parity: the HIP path (through the drop-in autograd surface -> ctypes -> C ABI) against
+the CPU oracle on the same seeded inputs.
+
+Bars: radii / tiles_touched / offsets / sorted point_list / ranges exact;
+rendered RGB within 1e-5 absolute on pixels whose accept/reject decisions are not within the
+oracle's margin of a threshold; n_contrib exact on those pixels; gradients within
+1e-5 * max|g| (norm-wise: the reference's own atomics make them order-dependent).
+"""
+import numpy as np
+import pytest
+import torch
+
+import gsr_scene
+import util
+
+pytestmark = pytest.mark.gpu
+
+IMG_ATOL = 1e-5
+GRAD_RTOL = 1e-5
+
+
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+
+
+def check_forward(h, o, cam):
+    P = o["P"]
+    assert h["num_rendered"] == o["num_rendered"]
+    np.testing.assert_array_equal(h["radii"], o["radii"])
+    np.testing.assert_array_equal(h["tiles_touched"], o["tiles_touched"])
+    np.testing.assert_array_equal(h["point_offsets"], o["point_offsets"])
+    vis = o["radii"] > 0
+    # per-Gaussian floats: bit-exact (same expression order, no FMA contraction on either side)
+    for k in ("means2D", "conic_opacity", "rgb", "depths"):
+        a, b = h[k][vis], o[k][vis]
+        assert np.array_equal(a, b), f"{k}: max abs diff {np.abs(a - b).max()}"
+    cb = (o["clamped"][:, 0] | (o["clamped"][:, 1] << 1) | (o["clamped"][:, 2] << 2)).astype(np.uint8)
+    np.testing.assert_array_equal(h["clamped_bits"][vis], cb[vis])
+    if o["num_rendered"] > 0:
+        np.testing.assert_array_equal(h["point_list"], o["point_list"])
+        np.testing.assert_array_equal(h["keys"], o["keys"])
+    np.testing.assert_array_equal(h["ranges"], o["ranges"])
+    ok = o["fragile"] == 0
+    frac = 1.0 - ok.mean()
+    assert frac < 5e-3, f"too many fragile pixels: {frac}"
+    np.testing.assert_array_equal(h["n_contrib"][ok], o["n_contrib"][ok])
+    H, W = cam.image_height, cam.image_width
+    err = np.abs(h["color"].reshape(3, -1) - o["color"].reshape(3, -1))[:, ok]
+    assert err.max() <= IMG_ATOL, f"image max abs err {err.max()} (mean {err.mean()})"
+    errT = np.abs(h["final_T"] - o["final_T"])[ok]
+    assert errT.max() <= IMG_ATOL
+    return err.max()
+
+
+def check_grads(h, og, names):
+    for k in names:
+        a, b = h["grads"][k], og[k]
+        scale = max(np.abs(b).max(), 1e-20)
+        err = np.abs(a - b).max() / scale
+        assert err <= GRAD_RTOL, f"{k}: max abs err / max|g| = {err:.3e} (max|g| = {scale:.3e})"
+
+
+CASES = [
+    # name, P, W, H, D, mu, seed
+    ("c1_like", 10_000, 256, 256, 0, -3.5, 0),
+    ("partial_tiles_deg3", 3_000, 200, 120, 3, -3.0, 3),
+    ("deg1", 2_000, 97, 61, 1, -2.5, 5),
+    ("deg2_big_splats", 500, 160, 96, 2, -1.5, 6),
+]
+
+
+@pytest.mark.parametrize("name,P,W,H,D,mu,seed", CASES)
+def test_forward_backward_vs_oracle(name, P, W, H, D, mu, seed):
+    _need_gpu()
+    scene = gsr_scene.make_scene(P, mu, sh_degree=D, seed=seed)
+    cam = gsr_scene.make_camera(W, H)
+    o = util.oracle_forward(scene, cam, D)
+    dpix = util.fragile_free_dpix(o, cam)
+    h = util.hip_forward_backward(scene, cam, D, dpix)
+    check_forward(h, o, cam)
+    og = util.oracle.backward(o, dpix.numpy())
+    check_grads(h, og, ["dL_dmeans3D", "dL_dmeans2D", "dL_dopacity", "dL_dsh", "dL_dscales", "dL_drotations"])
+
+
+def test_rotated_camera_and_sh_degree_below_max():
+    """16 coefficients stored but active degree 1 (training's early phase): unused dL_dsh rows are 0."""
+    _need_gpu()
+    scene = gsr_scene.make_scene(4_000, -3.0, sh_degree=3, seed=11)
+    cam = gsr_scene.ring_camera(320, 180, k=3, n=8)
+    o = util.oracle_forward(scene, cam, 1)
+    dpix = util.fragile_free_dpix(o, cam)
+    h = util.hip_forward_backward(scene, cam, 1, dpix)
+    check_forward(h, o, cam)
+    og = util.oracle.backward(o, dpix.numpy())
+    check_grads(h, og, ["dL_dmeans3D", "dL_dmeans2D", "dL_dopacity", "dL_dsh", "dL_dscales", "dL_drotations"])
+    assert np.all(h["grads"]["dL_dsh"][:, 4:, :] == 0)
+
+
+def test_precomputed_colors_and_cov3d_and_scale_modifier():
+    _need_gpu()
+    scene = gsr_scene.make_scene(2_500, -3.0, sh_degree=0, seed=21)
+    cam = gsr_scene.make_camera(180, 100)
+    g = torch.Generator().manual_seed(5)
+    colors = torch.rand(2_500, 3, generator=g)
+    # covariances from the oracle's own computeCov3D at scale_modifier 1.3
+    o0 = util.oracle_forward(scene, cam, 0, scale_modifier=1.3)
+    cov = torch.from_numpy(o0["cov3D"].copy())
+    vis = o0["radii"] > 0
+    cov[~torch.from_numpy(vis)] = torch.eye(3)[[0, 0, 0, 1, 1, 2], [0, 1, 2, 1, 2, 2]] * 1e-4
+    o = util.oracle_forward(scene, cam, 0, colors_precomp=colors, cov3D_precomp=cov, use_sh=False, use_scale_rot=False)
+    dpix = util.fragile_free_dpix(o, cam)
+    h = util.hip_forward_backward(scene, cam, 0, dpix, colors_precomp=colors, cov3D_precomp=cov, use_sh=False,
+                                  use_scale_rot=False)
+    check_forward(h, o, cam)
+    og = util.oracle.backward(o, dpix.numpy())
+    check_grads(h, og, ["dL_dmeans3D", "dL_dmeans2D", "dL_dopacity", "dL_dcolors", "dL_dcov3D"])
+    # scale_modifier path with scales/rotations
+    o2 = util.oracle_forward(scene, cam, 0, scale_modifier=1.3)
+    dpix2 = util.fragile_free_dpix(o2, cam)
+    h2 = util.hip_forward_backward(scene, cam, 0, dpix2, scale_modifier=1.3)
+    check_forward(h2, o2, cam)
+    og2 = util.oracle.backward(o2, dpix2.numpy())
+    check_grads(h2, og2, ["dL_dmeans3D", "dL_dopacity", "dL_dsh", "dL_dscales", "dL_drotations"])
+
+
+def test_edge_cases_empty_scene_and_nothing_visible():
+    _need_gpu()
+    from diff_gaussian_rasterization import GaussianRasterizer
+    dev = torch.device("cuda:0")
+    cam = gsr_scene.make_camera(64, 48)
+    scene = gsr_scene.make_scene(10, -3.0, sh_degree=0, seed=1)
+    settings = util.hip_settings(scene, cam, 0, dev)
+    # P == 0: image stays zero-filled, not background (rasterize_points.cu:94,129)
+    e3 = torch.zeros(0, 3, device=dev)
+    color, radii = GaussianRasterizer(settings)(means3D=e3, means2D=e3.clone(), opacities=torch.zeros(0, 1, device=dev),
+                                                shs=torch.zeros(0, 1, 3, device=dev), scales=e3.clone(),
+                                                rotations=torch.zeros(0, 4, device=dev))
+    assert color.shape == (3, 48, 64) and radii.shape == (0,)
+    assert float(color.abs().max()) == 0.0
+    # everything behind the camera: R == 0, every pixel is background (T = 1), grads are zero
+    behind = gsr_scene.Scene(scene.means3D - torch.tensor([0.0, 0.0, 100.0]), scene.scales, scene.rotations,
+                             scene.opacities, scene.shs, scene.bg)
+    dpix = torch.ones(3, 48, 64)
+    h = util.hip_forward_backward(behind, cam, 0, dpix)
+    assert h["num_rendered"] == 0 and np.all(h["radii"] == 0)
+    np.testing.assert_array_equal(h["color"], np.broadcast_to(scene.bg.numpy()[:, None, None], (3, 48, 64)))
+    for k, v in h["grads"].items():
+        assert np.all(v == 0), k
+
+
+def test_mark_visible():
+    _need_gpu()
+    from diff_gaussian_rasterization import GaussianRasterizer
+    dev = torch.device("cuda:0")
+    scene = gsr_scene.make_scene(5000, -3.0, sh_degree=0, seed=2)
+    cam = gsr_scene.ring_camera(64, 64, 1, 8, radius=1.0)
+    vis = GaussianRasterizer(util.hip_settings(scene, cam, 0, dev)).markVisible(scene.means3D.to(dev))
+    ref = util.oracle.mark_visible(scene.means3D.numpy(), cam.world_view_transform.numpy(), cam.full_proj_transform.numpy())
+    assert vis.dtype == torch.bool
+    np.testing.assert_array_equal(vis.cpu().numpy(), ref)
+    assert 0 < ref.sum() < 5000
+
+
+def test_validation_errors_match_reference_text():
+    _need_gpu()
+    from diff_gaussian_rasterization import GaussianRasterizer
+    dev = torch.device("cuda:0")
+    scene = gsr_scene.make_scene(10, -3.0, sh_degree=0, seed=1)
+    cam = gsr_scene.make_camera(32, 32)
+    r = GaussianRasterizer(util.hip_settings(scene, cam, 0, dev))
+    m = scene.means3D.to(dev)
+    with pytest.raises(Exception, match="Please provide excatly one of either SHs or precomputed colors!"):
+        r(means3D=m, means2D=m, opacities=scene.opacities.to(dev), scales=scene.scales.to(dev), rotations=scene.rotations.to(dev))
+    with pytest.raises(Exception, match="Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!"):
+        r(means3D=m, means2D=m, opacities=scene.opacities.to(dev), shs=scene.shs.to(dev), scales=scene.scales.to(dev))
+    # no CPU fallback: CPU tensors are refused loudly
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        r(means3D=scene.means3D, means2D=scene.means3D, opacities=scene.opacities, shs=scene.shs, scales=scene.scales,
+          rotations=scene.rotations)
+
+
+def test_prefiltered_flag_reports_instead_of_trapping():
+    _need_gpu()
+    from diff_gaussian_rasterization import GaussianRasterizer
+    dev = torch.device("cuda:0")
+    scene = gsr_scene.make_scene(100, -3.0, sh_degree=0, seed=1)
+    cam = gsr_scene.ring_camera(32, 32, 1, 8, radius=1.0)  # some points behind the camera
+    r = GaussianRasterizer(util.hip_settings(scene, cam, 0, dev, prefiltered=True))
+    m = scene.means3D.to(dev)
+    with pytest.raises(RuntimeError, match="filtered although prefiltered"):
+        r(means3D=m, means2D=m, opacities=scene.opacities.to(dev), shs=scene.shs.to(dev), scales=scene.scales.to(dev),
+          rotations=scene.rotations.to(dev))
+
+
+def test_smoke_entry():
+    _need_gpu()
+    import __graft_entry__
+    __graft_entry__.smoke()

@@ -1,0 +1,120 @@
+"""Shared helpers for the parity tests: run the HIP path (through the drop-in autograd surface /
+the ctypes `_C` binding, i.e. through the C ABI) and the CPU oracle on the same inputs."""
+import numpy as np
+import torch
+
+import gsr_scene
+from oracle import oracle
+
+
+def oracle_forward(scene, cam, D, margin=2e-5, colors_precomp=None, cov3D_precomp=None, scale_modifier=1.0,
+                   use_sh=True, use_scale_rot=True):
+    return oracle.forward(
+        scene.means3D.numpy(), scene.opacities.numpy(), cam.world_view_transform.numpy(),
+        cam.full_proj_transform.numpy(), cam.camera_center.numpy(), scene.bg.numpy(), cam.image_width,
+        cam.image_height, cam.tanfovx, cam.tanfovy, D,
+        shs=scene.shs.numpy() if use_sh else None,
+        colors_precomp=None if colors_precomp is None else colors_precomp.numpy(),
+        scales=scene.scales.numpy() if use_scale_rot else None,
+        rotations=scene.rotations.numpy() if use_scale_rot else None,
+        cov3D_precomp=None if cov3D_precomp is None else cov3D_precomp.numpy(),
+        scale_modifier=scale_modifier, margin=margin)
+
+
+def hip_settings(scene, cam, D, dev, scale_modifier=1.0, debug=False, prefiltered=False):
+    from diff_gaussian_rasterization import GaussianRasterizationSettings
+    return GaussianRasterizationSettings(
+        image_height=cam.image_height, image_width=cam.image_width, tanfovx=cam.tanfovx, tanfovy=cam.tanfovy,
+        bg=scene.bg.to(dev), scale_modifier=scale_modifier, viewmatrix=cam.world_view_transform.to(dev),
+        projmatrix=cam.full_proj_transform.to(dev), sh_degree=D, campos=cam.camera_center.to(dev),
+        prefiltered=prefiltered, debug=debug)
+
+
+def hip_forward_backward(scene, cam, D, dpix=None, dev="cuda:0", colors_precomp=None, cov3D_precomp=None,
+                         scale_modifier=1.0, use_sh=True, use_scale_rot=True, debug=False):
+    """Runs GaussianRasterizer fwd (+bwd when dpix is given) and returns numpy outputs, including
+    the intermediates read out of the opaque state buffers through the published layouts."""
+    from diff_gaussian_rasterization import GaussianRasterizer, _C, _RasterizeGaussians
+    dev = torch.device(dev)
+    leaf = lambda t: t.to(dev).clone().requires_grad_(True)
+    means = leaf(scene.means3D)
+    opac = leaf(scene.opacities)
+    means2D = torch.zeros_like(means, requires_grad=True)
+    kw = {}
+    if use_sh:
+        kw["shs"] = leaf(scene.shs)
+    else:
+        kw["colors_precomp"] = leaf(colors_precomp)
+    if use_scale_rot:
+        kw["scales"] = leaf(scene.scales)
+        kw["rotations"] = leaf(scene.rotations)
+    else:
+        kw["cov3D_precomp"] = leaf(cov3D_precomp)
+    settings = hip_settings(scene, cam, D, dev, scale_modifier, debug)
+    # capture the saved state buffers
+    captured = {}
+    orig = _C.rasterize_gaussians
+
+    def spy(*a):
+        r = orig(*a)
+        captured["R"], captured["geom"], captured["binning"], captured["img"] = r[0], r[3], r[4], r[5]
+        return r
+    _C.rasterize_gaussians = spy
+    try:
+        color, radii = GaussianRasterizer(settings)(means3D=means, means2D=means2D, opacities=opac, **kw)
+    finally:
+        _C.rasterize_gaussians = orig
+    out = dict(color=color.detach().cpu().numpy(), radii=radii.cpu().numpy(), num_rendered=captured["R"])
+    out.update(unpack_state(captured, means.shape[0], cam.image_width, cam.image_height))
+    if dpix is not None:
+        (color * dpix.to(dev)).sum().backward()
+        torch.cuda.synchronize()
+        g = dict(dL_dmeans3D=means.grad, dL_dmeans2D=means2D.grad, dL_dopacity=opac.grad)
+        if use_sh:
+            g["dL_dsh"] = kw["shs"].grad
+        else:
+            g["dL_dcolors"] = kw["colors_precomp"].grad
+        if use_scale_rot:
+            g["dL_dscales"] = kw["scales"].grad
+            g["dL_drotations"] = kw["rotations"].grad
+        else:
+            g["dL_dcov3D"] = kw["cov3D_precomp"].grad
+        out["grads"] = {k: v.cpu().numpy() for k, v in g.items()}
+    return out
+
+
+def unpack_state(cap, P, W, H):
+    from diff_gaussian_rasterization import _C
+    R = cap["R"]
+    o = {}
+    if P == 0:
+        return o
+    geom, img, binning = cap["geom"].cpu().numpy(), cap["img"].cpu().numpy(), cap["binning"].cpu().numpy()
+    gl, il = _C.geometry_layout(P), _C.image_layout(W, H)
+    N, T = W * H, ((W + 15) // 16) * ((H + 15) // 16)
+    splat = geom[gl.splat:gl.splat + 48 * P].view(np.float32).reshape(P, 12)
+    o["means2D"] = splat[:, 0:2]
+    o["conic_opacity"] = splat[:, 2:6]
+    o["rgb"] = splat[:, 6:9]
+    o["depths"] = geom[gl.depths:gl.depths + 4 * P].view(np.float32)
+    o["tiles_touched"] = geom[gl.tiles_touched:gl.tiles_touched + 4 * P].view(np.uint32)
+    o["point_offsets"] = geom[gl.point_offsets:gl.point_offsets + 4 * P].view(np.uint32)
+    o["clamped_bits"] = geom[gl.clamped:gl.clamped + P]
+    o["final_T"] = img[il.final_T:il.final_T + 4 * N].view(np.float32)
+    o["n_contrib"] = img[il.n_contrib:il.n_contrib + 4 * N].view(np.uint32)
+    o["ranges"] = img[il.ranges:il.ranges + 8 * T].view(np.uint32).reshape(T, 2)
+    if R > 0:
+        bl = _C.binning_layout(P, R, W, H)
+        o["point_list"] = binning[bl.point_list:bl.point_list + 4 * R].view(np.uint32)
+        o["keys"] = binning[bl.keys:bl.keys + 8 * R].view(np.uint64)
+    return o
+
+
+def fragile_free_dpix(o, cam, seed=1):
+    """Upstream gradient that is zero on pixels whose accept/reject decisions sit within the
+    oracle's margin of a threshold: a legitimate 1-ulp exp() difference there flips a pixel by up
+    to alpha*T and would leak into every gradient."""
+    g = torch.Generator().manual_seed(seed)
+    dpix = torch.randn(3, cam.image_height, cam.image_width, generator=g)
+    ok = torch.from_numpy((o["fragile"] == 0).reshape(cam.image_height, cam.image_width))
+    return dpix * ok
