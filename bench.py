@@ -46,13 +46,24 @@ def algorithmic_bytes(P, V, R, Rp, N, T, M):
     return fwd, bwd
 
 
+def host_cores():
+    """CPUs this process may actually use: cgroup quota if any, else the affinity mask."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def cpu_baseline(scene, cam, D):
     """The CPU oracle (a port: the reference has no CPU path and its CUDA sources cannot be built
     here) timed on one full step of the same workload, all host cores via OpenMP."""
-    import numpy as np
     from oracle import oracle
-    cores = os.cpu_count() or 1
-    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    cores = host_cores()
+    os.environ["OMP_NUM_THREADS"] = str(cores)  # read by libgomp when the oracle library is first loaded
     t0 = time.time()
     o = oracle.forward(scene.means3D.numpy(), scene.opacities.numpy(), cam.world_view_transform.numpy(),
                        cam.full_proj_transform.numpy(), cam.camera_center.numpy(), scene.bg.numpy(), cam.image_width,

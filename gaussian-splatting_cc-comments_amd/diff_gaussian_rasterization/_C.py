@@ -14,6 +14,10 @@ import os
 
 import torch
 
+# tests set this to keep the internal dL_dconic tensor of the last backward call in `debug_last`
+KEEP_DEBUG = False
+debug_last = {}
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(os.path.dirname(_HERE), "libgsr_hip.so")
 _lib = None
@@ -195,6 +199,8 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
                                   _ptr(dL_dcolors), _ptr(dL_dmeans3D), _ptr(dL_dcov3D), _ptr(dL_dsh), _ptr(dL_dscales),
                                   _ptr(dL_drotations), _stream(dev), int(bool(debug))))
             scratch.record_stream(torch.cuda.current_stream(dev))
+    if KEEP_DEBUG:
+        debug_last["dL_dconic"] = dL_dconic
     return dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations
 
 

@@ -122,9 +122,12 @@ def forward(means3D, opacities, viewmatrix, projmatrix, campos, bg, W, H, tanfov
     return s
 
 
-def backward(s, dL_dpix):
+def backward(s, dL_dpix, accum_mode=0):
     """Backward for a state returned by forward(); returns the 8 gradients of
-    rasterize_points.cu:215 (as float32) plus the double-precision per-Gaussian blend sums."""
+    rasterize_points.cu:215 (as float32) plus the double-precision per-Gaussian blend sums.
+    accum_mode 0: blend sums in double (the checker).  1 / 2: fp32 accumulation like the reference's
+    atomics, tiles visited in ascending / descending order -- two members of the family of results
+    the reference itself can return; their spread is the reference's own reproducibility band."""
     dL_dpix = _f32(dL_dpix)
     P, M, W, H = s["P"], s["M"], s["W"], s["H"]
     g = dict(dL_dmeans2D=np.zeros((P, 3), np.float32), dL_dcolors=np.zeros((P, 3), np.float32),
@@ -142,7 +145,7 @@ def backward(s, dL_dpix):
     lib().gsro_render_backward(W, H, _p(s["ranges"], _u), _p(s["point_list"], _u), _p(s["bg"], _f),
                                _p(s["means2D"], _f), _p(s["conic_opacity"], _f), _p(colors, _f),
                                _p(s["final_T"], _f), _p(s["n_contrib"], _u), _p(dL_dpix, _f), _p(m2, _d),
-                               _p(con, _d), _p(op, _d), _p(col, _d))
+                               _p(con, _d), _p(op, _d), _p(col, _d), int(accum_mode))
     g["dL_dmeans2D"][:, :2] = m2
     g["dL_dcolors"][:] = col
     g["dL_dopacity"][:, 0] = op
@@ -159,4 +162,26 @@ def backward(s, dL_dpix):
         _p(g["dL_dmeans3D"], _f), _p(g["dL_dcolors"], _f), _p(g["dL_dcov3D"], _f), _p(g["dL_dsh"], _f),
         _p(g["dL_dscales"], _f), _p(g["dL_drotations"], _f))
     g["blend64"] = dict(mean2D=m2, conic=con, opacity=op, colors=col)
+    return g
+
+
+def gaussian_backward(s, dL_dmeans2D, dL_dconic, dL_dcolors):
+    """Only BACKWARD::preprocess (backward.cu:144-277, 349-399) on caller-supplied blend sums
+    (dL_dmeans2D (P,3), dL_dconic (P,2,2), dL_dcolors (P,3), float32): lets a test feed the HIP
+    blend kernel's own sums to the oracle's per-Gaussian chain, so that stage is compared on
+    identical inputs."""
+    P, M, W, H = s["P"], s["M"], s["W"], s["H"]
+    m2 = _f32(dL_dmeans2D).reshape(P, 3)
+    conic4 = _f32(dL_dconic).reshape(P, 4)
+    g = dict(dL_dcolors=_f32(dL_dcolors).reshape(P, 3).copy(), dL_dmeans3D=np.zeros((P, 3), np.float32),
+             dL_dcov3D=np.zeros((P, 6), np.float32), dL_dsh=np.zeros((P, M, 3), np.float32),
+             dL_dscales=np.zeros((P, 3), np.float32), dL_drotations=np.zeros((P, 4), np.float32))
+    cov3D = s["cov3D_precomp"] if s["cov3D_precomp"] is not None else s["cov3D"]
+    lib().gsro_preprocess_backward(
+        P, s["D"], M, _p(s["means3D"], _f), _p(s["radii"], _i), _p(s["shs"], _f), _p(s["clamped"], _b),
+        _p(s["scales"], _f), _p(s["rotations"], _f), ctypes.c_float(s["scale_modifier"]), _p(cov3D, _f),
+        _p(s["viewmatrix"], _f), _p(s["projmatrix"], _f), W, H, ctypes.c_float(s["tanfovx"]),
+        ctypes.c_float(s["tanfovy"]), _p(s["campos"], _f), _p(m2, _f), _p(conic4, _f),
+        _p(g["dL_dmeans3D"], _f), _p(g["dL_dcolors"], _f), _p(g["dL_dcov3D"], _f), _p(g["dL_dsh"], _f),
+        _p(g["dL_dscales"], _f), _p(g["dL_drotations"], _f))
     return g

@@ -33,7 +33,8 @@ def check_forward(h, o, cam):
     vis = o["radii"] > 0
     # per-Gaussian floats: bit-exact (same expression order, no FMA contraction on either side)
     for k in ("means2D", "conic_opacity", "rgb", "depths"):
-        a, b = h[k][vis], o[k][vis]
+        ob = o["colors_precomp"] if (k == "rgb" and o["colors_precomp"] is not None) else o[k]
+        a, b = h[k][vis], ob[vis]
         assert np.array_equal(a, b), f"{k}: max abs diff {np.abs(a - b).max()}"
     cb = (o["clamped"][:, 0] | (o["clamped"][:, 1] << 1) | (o["clamped"][:, 2] << 2)).astype(np.uint8)
     np.testing.assert_array_equal(h["clamped_bits"][vis], cb[vis])
@@ -53,12 +54,44 @@ def check_forward(h, o, cam):
     return err.max()
 
 
-def check_grads(h, og, names):
+def _nerr(a, b):
+    return float(np.abs(a.astype(np.float64) - b.astype(np.float64)).max() / max(np.abs(b).max(), 1e-20))
+
+
+def check_grads(h, o, dpix, names):
+    """Three levels.
+    (1) backward blend kernel alone: its per-Gaussian sums (dL_dmean2D, dL_dconic, dL_dopacity,
+        dL_dcolors) against the oracle's double-precision sums, 1e-5 norm-wise.
+    (2) per-Gaussian chain alone: the HIP outputs against the oracle's chain evaluated on the HIP
+        kernel's OWN blend sums (identical inputs, same fp32 expression order): 1e-6.
+    (3) end to end through autograd: 1e-5 norm-wise, or the reference's own reproducibility band
+        where that is larger: its backward sums with fp32 atomics in hardware order, so two runs
+        of the reference differ; the oracle measures that spread by accumulating in fp32 in two
+        different tile orders (accum_mode 1 / 2) and the bar is max(1e-5, 2 x spread)."""
+    og = util.oracle.backward(o, dpix.numpy())
+    raw = h["raw_grads"]
+    P = o["P"]
+    report = []
+    g1 = util.oracle.backward(o, dpix.numpy(), accum_mode=1)
+    g2 = util.oracle.backward(o, dpix.numpy(), accum_mode=2)
+
+    def bar(k):
+        band = max(_nerr(g1[k], og[k]), _nerr(g2[k], og[k]), _nerr(g1[k], g2[k]))
+        return max(GRAD_RTOL, 2.0 * band)
+
+    for k in ("dL_dmeans2D", "dL_dconic", "dL_dopacity", "dL_dcolors"):
+        e = _nerr(raw[k].reshape(P, -1), og[k].reshape(P, -1))
+        report.append((f"blend:{k}", e, bar(k)))
+    oc = util.oracle.gaussian_backward(o, raw["dL_dmeans2D"], raw["dL_dconic"], raw["dL_dcolors"])
+    for k in ("dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales", "dL_drotations"):
+        if raw[k].size:
+            report.append((f"chain:{k}", _nerr(raw[k].reshape(P, -1), oc[k].reshape(P, -1)), 1e-6))
     for k in names:
-        a, b = h["grads"][k], og[k]
-        scale = max(np.abs(b).max(), 1e-20)
-        err = np.abs(a - b).max() / scale
-        assert err <= GRAD_RTOL, f"{k}: max abs err / max|g| = {err:.3e} (max|g| = {scale:.3e})"
+        report.append((f"e2e:{k}", _nerr(h["grads"][k], og[k]), bar(k)))
+    bad = [r for r in report if not (r[1] <= r[2])]
+    msg = "\n".join(f"{n:28s} err {e:.3e}  bar {b:.3e}" for n, e, b in report)
+    print(msg)
+    assert not bad, "gradient parity failed:\n" + msg
 
 
 CASES = [
@@ -79,8 +112,7 @@ def test_forward_backward_vs_oracle(name, P, W, H, D, mu, seed):
     dpix = util.fragile_free_dpix(o, cam)
     h = util.hip_forward_backward(scene, cam, D, dpix)
     check_forward(h, o, cam)
-    og = util.oracle.backward(o, dpix.numpy())
-    check_grads(h, og, ["dL_dmeans3D", "dL_dmeans2D", "dL_dopacity", "dL_dsh", "dL_dscales", "dL_drotations"])
+    check_grads(h, o, dpix, ["dL_dmeans3D", "dL_dmeans2D", "dL_dopacity", "dL_dsh", "dL_dscales", "dL_drotations"])
 
 
 def test_rotated_camera_and_sh_degree_below_max():
@@ -92,8 +124,7 @@ def test_rotated_camera_and_sh_degree_below_max():
     dpix = util.fragile_free_dpix(o, cam)
     h = util.hip_forward_backward(scene, cam, 1, dpix)
     check_forward(h, o, cam)
-    og = util.oracle.backward(o, dpix.numpy())
-    check_grads(h, og, ["dL_dmeans3D", "dL_dmeans2D", "dL_dopacity", "dL_dsh", "dL_dscales", "dL_drotations"])
+    check_grads(h, o, dpix, ["dL_dmeans3D", "dL_dmeans2D", "dL_dopacity", "dL_dsh", "dL_dscales", "dL_drotations"])
     assert np.all(h["grads"]["dL_dsh"][:, 4:, :] == 0)
 
 
@@ -113,15 +144,13 @@ def test_precomputed_colors_and_cov3d_and_scale_modifier():
     h = util.hip_forward_backward(scene, cam, 0, dpix, colors_precomp=colors, cov3D_precomp=cov, use_sh=False,
                                   use_scale_rot=False)
     check_forward(h, o, cam)
-    og = util.oracle.backward(o, dpix.numpy())
-    check_grads(h, og, ["dL_dmeans3D", "dL_dmeans2D", "dL_dopacity", "dL_dcolors", "dL_dcov3D"])
+    check_grads(h, o, dpix, ["dL_dmeans3D", "dL_dmeans2D", "dL_dopacity", "dL_dcolors", "dL_dcov3D"])
     # scale_modifier path with scales/rotations
     o2 = util.oracle_forward(scene, cam, 0, scale_modifier=1.3)
     dpix2 = util.fragile_free_dpix(o2, cam)
     h2 = util.hip_forward_backward(scene, cam, 0, dpix2, scale_modifier=1.3)
     check_forward(h2, o2, cam)
-    og2 = util.oracle.backward(o2, dpix2.numpy())
-    check_grads(h2, og2, ["dL_dmeans3D", "dL_dopacity", "dL_dsh", "dL_dscales", "dL_drotations"])
+    check_grads(h2, o2, dpix2, ["dL_dmeans3D", "dL_dopacity", "dL_dsh", "dL_dscales", "dL_drotations"])
 
 
 def test_edge_cases_empty_scene_and_nothing_visible():

@@ -67,8 +67,25 @@ def hip_forward_backward(scene, cam, D, dpix=None, dev="cuda:0", colors_precomp=
     out = dict(color=color.detach().cpu().numpy(), radii=radii.cpu().numpy(), num_rendered=captured["R"])
     out.update(unpack_state(captured, means.shape[0], cam.image_width, cam.image_height))
     if dpix is not None:
-        (color * dpix.to(dev)).sum().backward()
-        torch.cuda.synchronize()
+        raw = {}
+        orig_b = _C.rasterize_gaussians_backward
+
+        def spy_b(*a):
+            r = orig_b(*a)
+            for k, t in zip(("dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh",
+                             "dL_dscales", "dL_drotations"), r):
+                raw[k] = t
+            raw["dL_dconic"] = _C.debug_last["dL_dconic"]
+            return r
+        _C.rasterize_gaussians_backward = spy_b
+        _C.KEEP_DEBUG = True
+        try:
+            color.backward(dpix.to(dev))
+            torch.cuda.synchronize()
+        finally:
+            _C.rasterize_gaussians_backward = orig_b
+            _C.KEEP_DEBUG = False
+        out["raw_grads"] = {k: v.cpu().numpy() for k, v in raw.items()}
         g = dict(dL_dmeans3D=means.grad, dL_dmeans2D=means2D.grad, dL_dopacity=opac.grad)
         if use_sh:
             g["dL_dsh"] = kw["shs"].grad
