@@ -5,8 +5,8 @@
 
 One "step" = one forward + one backward of the drop-in GaussianRasterizer over one synthetic view
 (inputs resident in HBM).  With N > 1 every rank renders its own view of the replicated scene and
-the per-step parameter gradients (59 floats per Gaussian) are summed with one RCCL all-reduce per
-tensor; value = views per second over all ranks (weak scaling).  Prints ONE JSON line on rank 0.
+the per-step parameter gradients (59 floats per Gaussian) are summed with ONE RCCL all-reduce of a
+flat bucket; value = views per second over all ranks (weak scaling).  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
@@ -114,6 +114,10 @@ def main():
     g = torch.Generator().manual_seed(1 + rank)
     dpix = to(torch.randn(3, H, W, generator=g))
     state = {}
+    bucket = None
+    if world > 1:
+        import view_parallel
+        bucket = view_parallel.GradientBucket(params.values())  # one flat 59-floats-per-Gaussian RCCL all-reduce
 
     def step():
         for p in params.values():
@@ -122,9 +126,7 @@ def main():
         color, radii = rasterizer(means3D=params["means3D"], means2D=means2D, **{k: v for k, v in params.items() if k != "means3D"})
         color.backward(dpix)
         if world > 1:  # view-parallel: sum the 59 floats/Gaussian of parameter gradients over ranks
-            works = [dist.all_reduce(p.grad, async_op=True) for p in params.values()]
-            for w_ in works:
-                w_.wait()
+            bucket.all_reduce()
         state["color"], state["radii"] = color, radii
 
     for _ in range(args.warmup):

@@ -185,3 +185,25 @@ def gaussian_backward(s, dL_dmeans2D, dL_dconic, dL_dcolors):
         _p(g["dL_dmeans3D"], _f), _p(g["dL_dcolors"], _f), _p(g["dL_dcov3D"], _f), _p(g["dL_dsh"], _f),
         _p(g["dL_dscales"], _f), _p(g["dL_drotations"], _f))
     return g
+
+
+def sh_forward(deg, pos, campos, shs):
+    """forward.cu:21-81 on its own -> (rgb (n,3), clamped (n,3) uint8)."""
+    pos, campos, shs = _f32(pos), _f32(campos), _f32(shs)
+    n, M = pos.shape[0], shs.shape[1]
+    rgb = np.zeros((n, 3), np.float32)
+    clamped = np.zeros((n, 3), np.uint8)
+    lib().gsro_sh_forward(n, deg, M, _p(pos, _f), _p(campos, _f), _p(shs, _f), _p(rgb, _f), _p(clamped, _b))
+    return rgb, clamped
+
+
+def sh_backward(deg, pos, campos, shs, clamped, dL_dcolor):
+    """backward.cu:20-139 on its own -> (dL_dmean (n,3) view-direction term only, dL_dsh (n,M,3))."""
+    pos, campos, shs, dL_dcolor = _f32(pos), _f32(campos), _f32(shs), _f32(dL_dcolor)
+    clamped = np.ascontiguousarray(clamped, dtype=np.uint8)
+    n, M = pos.shape[0], shs.shape[1]
+    dmean = np.zeros((n, 3), np.float32)
+    dsh = np.zeros((n, M, 3), np.float32)
+    lib().gsro_sh_backward(n, deg, M, _p(pos, _f), _p(campos, _f), _p(shs, _f), _p(clamped, _b), _p(dL_dcolor, _f),
+                           _p(dmean, _f), _p(dsh, _f))
+    return dmean, dsh

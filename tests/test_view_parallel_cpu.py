@@ -1,0 +1,53 @@
+"""CPU: the N>1 path (view sharding + one flat-bucket gradient all-reduce) with gloo, world_size 2."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import view_parallel
+
+
+def test_shard_views_partition():
+    for world in (1, 2, 3, 8):
+        seen = sorted(v for r in range(world) for v in view_parallel.shard_views(19, r, world))
+        assert seen == list(range(19))
+    assert view_parallel.shard_views(8, 3, 8) == [3]
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, P):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = torch.Generator().manual_seed(0)
+        shapes = [(P, 3), (P, 16, 3), (P, 1), (P, 3), (P, 4)]  # xyz, SH, opacity, scale, rotation = 59 floats
+        params = [torch.zeros(s, requires_grad=True) for s in shapes]
+        base = [torch.randn(s, generator=g) for s in shapes]
+        for p, b in zip(params, base):
+            p.grad = b * (rank + 1)  # what "this rank's view" contributed
+        bucket = view_parallel.GradientBucket(params)
+        assert bucket.numel == 59 * P
+        bucket.all_reduce()
+        tot = sum(range(1, world + 1))
+        for p, b in zip(params, base):
+            assert torch.allclose(p.grad, b * tot)
+            assert p.grad.data_ptr() >= bucket.flat.data_ptr()  # aliases the bucket, no unpack copy
+        radii = torch.tensor([rank, 5 - rank, 7], dtype=torch.int32)
+        m = view_parallel.all_reduce_max_radii(radii)
+        assert m.tolist() == [world - 1, 5, 7]
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gradient_bucket_all_reduce_gloo_world2():
+    mp.spawn(_worker, args=(2, _free_port(), 257), nprocs=2, join=True)
