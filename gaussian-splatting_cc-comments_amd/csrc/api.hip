@@ -109,13 +109,16 @@ extern "C" int gsr_geometry_layout_of(int P, gsr_geometry_layout* o)
 	const size_t n = (size_t)P;
 	const size_t nb = (n + GSR_PREPROCESS_BLOCK - 1) / GSR_PREPROCESS_BLOCK;
 	size_t off = 0;
-	o->splat = off;         off = gsr_align_up(off + n * sizeof(GsrSplat));
-	o->depths = off;        off = gsr_align_up(off + n * 4);
-	o->tiles_touched = off; off = gsr_align_up(off + n * 4);
-	o->point_offsets = off; off = gsr_align_up(off + n * 4);
-	o->clamped = off;       off = gsr_align_up(off + n);
-	o->status = off;        off = gsr_align_up(off + 4 * 4);
-	o->scan_temp = off;     off = gsr_align_up(off + nb * 4);
+	o->splat = off;          off = gsr_align_up(off + n * sizeof(GsrSplat));
+	o->depth_keys = off;     off = gsr_align_up(off + n * 4);
+	o->depth_keys_alt = off; off = gsr_align_up(off + n * 4);
+	o->perm = off;           off = gsr_align_up(off + n * 4);
+	o->perm_alt = off;       off = gsr_align_up(off + n * 4);
+	o->tiles_touched = off;  off = gsr_align_up(off + n * 4);
+	o->clamped = off;        off = gsr_align_up(off + n);
+	o->status = off;         off = gsr_align_up(off + 4 * 4);
+	o->scan_temp = off;      off = gsr_align_up(off + 2 * gsr_align_up(nb * 4));
+	o->sort_table = off;     off = gsr_align_up(off + gsr_radix_table_bytes(n));
 	o->total = off;
 	return GSR_OK;
 }
@@ -139,12 +142,11 @@ extern "C" int gsr_binning_layout_of(int P, int64_t R, int W, int H, gsr_binning
 	if (R < 0 || !o) return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "gsr_binning_layout_of: bad arguments");
 	const size_t n = (size_t)R;
 	size_t off = 0;
-	o->point_list = off;          off = gsr_align_up(off + n * 4);
-	o->point_list_unsorted = off; off = gsr_align_up(off + n * 4);
-	o->keys = off;                off = gsr_align_up(off + n * 8);
-	o->keys_unsorted = off;       off = gsr_align_up(off + n * 8);
-	o->sort_temp_bytes = gsr_sort_temp_bytes(R);
-	o->sort_temp = off;           off = gsr_align_up(off + o->sort_temp_bytes);
+	o->point_list = off;     off = gsr_align_up(off + n * 4);
+	o->point_list_alt = off; off = gsr_align_up(off + n * 4);
+	o->tile_keys = off;      off = gsr_align_up(off + n * 4);
+	o->tile_keys_alt = off;  off = gsr_align_up(off + n * 4);
+	o->sort_table = off;     off = gsr_align_up(off + gsr_radix_table_bytes(n));
 	o->total = off;
 	return GSR_OK;
 }
@@ -175,15 +177,20 @@ GsrGeometry gsr_geometry_view(void* blob, int P)
 {
 	gsr_geometry_layout l;
 	gsr_geometry_layout_of(P, &l);
+	const size_t nb = ((size_t)P + GSR_PREPROCESS_BLOCK - 1) / GSR_PREPROCESS_BLOCK;
 	char* b = (char*)blob;
 	GsrGeometry g;
 	g.splat = (GsrSplat*)(b + l.splat);
-	g.depths = (float*)(b + l.depths);
+	g.depth_keys = (uint32_t*)(b + l.depth_keys);
+	g.depth_keys_alt = (uint32_t*)(b + l.depth_keys_alt);
+	g.perm = (uint32_t*)(b + l.perm);
+	g.perm_alt = (uint32_t*)(b + l.perm_alt);
 	g.tiles_touched = (uint32_t*)(b + l.tiles_touched);
-	g.point_offsets = (uint32_t*)(b + l.point_offsets);
 	g.clamped = (uint8_t*)(b + l.clamped);
 	g.status = (uint32_t*)(b + l.status);
 	g.block_sums = (uint32_t*)(b + l.scan_temp);
+	g.sorted_block_sums = (uint32_t*)(b + l.scan_temp + gsr_align_up(nb * 4));
+	g.sort_table = (void*)(b + l.sort_table);
 	return g;
 }
 
@@ -207,11 +214,10 @@ GsrBinning gsr_binning_view(void* blob, int P, int64_t R, int W, int H)
 	char* b = (char*)blob;
 	GsrBinning bn;
 	bn.point_list = (uint32_t*)(b + l.point_list);
-	bn.point_list_unsorted = (uint32_t*)(b + l.point_list_unsorted);
-	bn.keys = (uint64_t*)(b + l.keys);
-	bn.keys_unsorted = (uint64_t*)(b + l.keys_unsorted);
-	bn.sort_temp = (void*)(b + l.sort_temp);
-	bn.sort_temp_bytes = l.sort_temp_bytes;
+	bn.point_list_alt = (uint32_t*)(b + l.point_list_alt);
+	bn.tile_keys = (uint32_t*)(b + l.tile_keys);
+	bn.tile_keys_alt = (uint32_t*)(b + l.tile_keys_alt);
+	bn.sort_table = (void*)(b + l.sort_table);
 	return bn;
 }
 
@@ -275,16 +281,33 @@ extern "C" int gsr_forward_preprocess(int P, int D, int M, int width, int height
 		gsr_launch_preprocess(a, s);
 	}
 	if ((rc = gsr_stage_done(s, debug, "preprocess"))) return rc;
+	const int nb = (P + GSR_PREPROCESS_BLOCK - 1) / GSR_PREPROCESS_BLOCK;
 	{
 		GsrProfScope p(s, "scan");
-		gsr_launch_scan_block_sums(a.g, P, s);
-		gsr_launch_finalize_offsets(a.g, P, s);
+		gsr_launch_scan_block_sums(a.g.block_sums, nb, a.g.status + 1, s);
 	}
 	if ((rc = gsr_stage_done(s, debug, "scan"))) return rc;
 
-	uint32_t status_host[2] = {0, 0};
+	// read num_rendered back; the per-Gaussian half of the sort is enqueued behind the copy and keeps
+	// the GPU busy while the host waits on the event, allocates the binning buffer and launches stage 2
+	static thread_local uint32_t* status_host = nullptr;  // pinned, reused
+	static thread_local hipEvent_t ev = nullptr;
+	if (!status_host) {
+		if ((rc = gsr_check_hip(hipHostMalloc((void**)&status_host, 16, hipHostMallocDefault), "hipHostMalloc"))) return rc;
+		if ((rc = gsr_check_hip(hipEventCreateWithFlags(&ev, hipEventDisableTiming), "hipEventCreate"))) return rc;
+	}
 	if ((rc = gsr_check_hip(hipMemcpyAsync(status_host, a.g.status, 8, hipMemcpyDeviceToHost, s), "hipMemcpyAsync(num_rendered)"))) return rc;
-	if ((rc = gsr_check_hip(hipStreamSynchronize(s), "hipStreamSynchronize(preprocess)"))) return rc;
+	if ((rc = gsr_check_hip(hipEventRecord(ev, s), "hipEventRecord"))) return rc;
+	{
+		GsrProfScope p(s, "depth_sort");
+		int in_first = 1;
+		gsr_radix_sort_u32(a.g.depth_keys, a.g.perm, a.g.depth_keys_alt, a.g.perm_alt, (size_t)P, 32, a.g.sort_table, &in_first, s);
+		// 32 bits = 4 passes: the result is back in (depth_keys, perm)
+		gsr_launch_sorted_block_sums(a.g, P, s);
+		gsr_launch_scan_block_sums(a.g.sorted_block_sums, nb, nullptr, s);
+	}
+	if ((rc = gsr_stage_done(s, debug, "depth_sort"))) return rc;
+	if ((rc = gsr_check_hip(hipEventSynchronize(ev), "hipEventSynchronize(num_rendered)"))) return rc;
 	if (status_host[0] & 1u)
 		return gsr_fail(GSR_ERR_PREFILTERED, "Point is filtered although prefiltered is set. This shouldn't happen!");
 	*num_rendered_host = (int64_t)status_host[1];
@@ -314,21 +337,26 @@ extern "C" int gsr_forward_render(int P, int64_t R, int width, int height, const
 	memset(&b, 0, sizeof b);
 	if (R > 0) {
 		b = gsr_binning_view(binning, P, R, width, height);
+		const int bit = (int)gsr_get_higher_msb((uint32_t)ntiles);  // key bits above the depth word, rasterizer_impl.cu:355
+		// emit into whichever buffer pair makes the ping-pong sort finish in (tile_keys, point_list)
+		const bool even = gsr_radix_num_passes(bit) % 2 == 0;
+		uint32_t *k0 = even ? b.tile_keys : b.tile_keys_alt, *v0 = even ? b.point_list : b.point_list_alt;
+		uint32_t *k1 = even ? b.tile_keys_alt : b.tile_keys, *v1 = even ? b.point_list_alt : b.point_list;
 		{
 			GsrProfScope p(s, "duplicate_keys");
-			gsr_launch_duplicate_keys(g, radii, P, width, height, b, s);
+			gsr_launch_duplicate_keys(g, P, width, k0, v0, s);
 		}
 		if ((rc = gsr_stage_done(s, debug, "duplicate_keys"))) return rc;
-		const int bit = (int)gsr_get_higher_msb((uint32_t)ntiles);
 		{
 			GsrProfScope p(s, "sort");
-			if ((rc = gsr_sort_pairs(b, R, 32 + bit, s))) return rc;
+			int in_first = 1;
+			gsr_radix_sort_u32(k0, v0, k1, v1, (size_t)R, bit, b.sort_table, &in_first, s);
 		}
 		if ((rc = gsr_stage_done(s, debug, "sort"))) return rc;
 	}
 	{
 		GsrProfScope p(s, "tile_ranges");
-		gsr_launch_tile_ranges(b.keys, R, im.ranges, ntiles, s);
+		gsr_launch_tile_ranges(b.tile_keys, R, im.ranges, ntiles, s);
 	}
 	if ((rc = gsr_stage_done(s, debug, "tile_ranges"))) return rc;
 	{

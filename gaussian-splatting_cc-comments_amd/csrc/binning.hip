@@ -1,16 +1,16 @@
-// binning.hip -- tile-count prefix sum, (tile|depth) key emission, sort, tile ranges.
+// binning.hip -- instance counting, depth-ordered (tile) key emission, tile ranges.
 //
-// Replaces cub::DeviceScan::InclusiveSum (rasterizer_impl.cu:323), duplicateWithKeys (:78-126),
-// cub::DeviceRadixSort::SortPairs on bits [0,32+bit) (:357-374) and identifyTileRanges (:133-159).
+// Replaces cub::DeviceScan::InclusiveSum (rasterizer_impl.cu:323), duplicateWithKeys (:78-126)
+// and identifyTileRanges (:133-159).  Together with sort.hip it produces the same sorted instance
+// list and tile ranges as the reference's 64-bit (tile | depth) sort:
+//   stage 1 (per Gaussian, before the host learns num_rendered):
+//     preprocess writes depth bits as sort keys -> stable radix sort of the P Gaussians by depth
+//     -> per-workgroup sums of tiles_touched in depth order -> their exclusive scan
+//   stage 2 (per instance): emit (tile id, Gaussian id) pairs in depth order -> stable radix sort
+//     by tile id -> tile ranges.
 #include "gsr_internal.h"
 
-#include <cstring>
-#include <rocprim/device/device_radix_sort.hpp>
-
-// ---- prefix sum over tiles_touched ---------------------------------------------------------
-// Stage A (in the preprocess kernel): block_sums[b] = sum of tiles_touched over workgroup b.
-// Stage B (here, one workgroup): block_sums -> exclusive prefix, grand total -> status[1].
-// Stage C (gsr_finalize_offsets_kernel): in-workgroup inclusive scan + block prefix.
+// ---- workgroup scan helpers ------------------------------------------------------------------
 __device__ __forceinline__ uint32_t gsr_wave_incl_scan(uint32_t v)
 {
 	const int lane = threadIdx.x & 63;
@@ -22,9 +22,9 @@ __device__ __forceinline__ uint32_t gsr_wave_incl_scan(uint32_t v)
 	return v;
 }
 
-// inclusive scan across a 1024- or 256-thread workgroup; returns inclusive value, *total = sum
+// inclusive scan across a BLOCK-thread workgroup; returns the inclusive value, *total = sum
 template <int BLOCK>
-__device__ __forceinline__ uint32_t gsr_block_incl_scan(uint32_t v, uint32_t* total, uint32_t* lds /* BLOCK/64+1 */)
+__device__ __forceinline__ uint32_t gsr_block_incl_scan(uint32_t v, uint32_t* total, uint32_t* lds /* BLOCK/64 */)
 {
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	uint32_t incl = gsr_wave_incl_scan(v);
@@ -42,78 +42,86 @@ __device__ __forceinline__ uint32_t gsr_block_incl_scan(uint32_t v, uint32_t* to
 	return incl + base;
 }
 
-__global__ void __launch_bounds__(1024) gsr_scan_block_sums_kernel(uint32_t* block_sums, int nb, uint32_t* status)
+// block_sums (per 256-Gaussian workgroup) -> exclusive prefix in place; grand total -> *total_out
+__global__ void __launch_bounds__(1024) gsr_scan_block_sums_kernel(uint32_t* block_sums, int nb, uint32_t* total_out)
 {
-	__shared__ uint32_t lds[1024 / 64 + 1];
+	__shared__ uint32_t lds[1024 / 64];
 	uint32_t carry = 0;
 	for (int base = 0; base < nb; base += 1024) {
 		const int i = base + threadIdx.x;
 		uint32_t v = (i < nb) ? block_sums[i] : 0u;
 		uint32_t total;
 		uint32_t incl = gsr_block_incl_scan<1024>(v, &total, lds);
-		if (i < nb) block_sums[i] = carry + incl - v;  // exclusive
+		if (i < nb) block_sums[i] = carry + incl - v;
 		carry += total;
 	}
-	if (threadIdx.x == 0) status[1] = carry;
+	if (threadIdx.x == 0 && total_out) *total_out = carry;
 }
 
-void gsr_launch_scan_block_sums(GsrGeometry g, int P, hipStream_t s)
+void gsr_launch_scan_block_sums(uint32_t* block_sums, int nb, uint32_t* total_out, hipStream_t s)
 {
-	const int nb = (P + GSR_PREPROCESS_BLOCK - 1) / GSR_PREPROCESS_BLOCK;
-	hipLaunchKernelGGL(gsr_scan_block_sums_kernel, dim3(1), dim3(1024), 0, s, g.block_sums, nb, g.status);
+	hipLaunchKernelGGL(gsr_scan_block_sums_kernel, dim3(1), dim3(1024), 0, s, block_sums, nb, total_out);
 }
 
-__global__ void __launch_bounds__(GSR_PREPROCESS_BLOCK) gsr_finalize_offsets_kernel(GsrGeometry g, int P)
+// per-workgroup sums of tiles_touched taken in depth order (perm = Gaussian ids sorted by depth)
+__global__ void __launch_bounds__(GSR_PREPROCESS_BLOCK) gsr_sorted_block_sums_kernel(const uint32_t* __restrict__ perm,
+                                                                                    const uint32_t* __restrict__ tiles_touched,
+                                                                                    int P, uint32_t* __restrict__ sums)
 {
-	__shared__ uint32_t lds[GSR_PREPROCESS_BLOCK / 64 + 1];
-	const int idx = blockIdx.x * GSR_PREPROCESS_BLOCK + threadIdx.x;
-	const uint32_t t = (idx < P) ? g.tiles_touched[idx] : 0u;
+	__shared__ uint32_t lds[GSR_PREPROCESS_BLOCK / 64];
+	const int i = blockIdx.x * GSR_PREPROCESS_BLOCK + threadIdx.x;
+	const uint32_t t = (i < P) ? tiles_touched[perm[i]] : 0u;
 	uint32_t total;
-	const uint32_t incl = gsr_block_incl_scan<GSR_PREPROCESS_BLOCK>(t, &total, lds) + g.block_sums[blockIdx.x];
-	if (idx < P) {
-		g.point_offsets[idx] = incl;
-		if (t) g.splat[idx].slot_base = incl - t;
-	}
+	(void)gsr_block_incl_scan<GSR_PREPROCESS_BLOCK>(t, &total, lds);
+	if (threadIdx.x == 0) sums[blockIdx.x] = total;
 }
 
-void gsr_launch_finalize_offsets(GsrGeometry g, int P, hipStream_t s)
+void gsr_launch_sorted_block_sums(GsrGeometry g, int P, hipStream_t s)
 {
 	const int nb = (P + GSR_PREPROCESS_BLOCK - 1) / GSR_PREPROCESS_BLOCK;
-	hipLaunchKernelGGL(gsr_finalize_offsets_kernel, dim3(nb), dim3(GSR_PREPROCESS_BLOCK), 0, s, g, P);
+	hipLaunchKernelGGL(gsr_sorted_block_sums_kernel, dim3(nb), dim3(GSR_PREPROCESS_BLOCK), 0, s, g.perm, g.tiles_touched, P,
+	                   g.sorted_block_sums);
 }
 
-// ---- key emission --------------------------------------------------------------------------
-// One Gaussian per lane for small rectangles; rectangles above GSR_DUP_COOP tiles are expanded
-// by the whole wave (lanes stride over the rectangle, so stores are contiguous runs).
+// ---- key emission ----------------------------------------------------------------------------
+// Thread i handles the i-th Gaussian in depth order.  Its first slot is the workgroup prefix plus
+// an in-workgroup scan, written back into the splat record (the backward blend addresses its
+// per-(Gaussian,tile) gradient slots with it).  Small rectangles are expanded by their own lane;
+// rectangles above GSR_DUP_COOP tiles by the whole wave, lanes striding over the rectangle so that
+// stores form contiguous runs.  Order inside a Gaussian: y outer, x inner (rasterizer_impl.cu:107-118).
 #define GSR_DUP_COOP 24
 
-__device__ __forceinline__ void gsr_emit(uint64_t* keys, uint32_t* vals, uint32_t off, uint32_t k, uint32_t minx,
-                                         uint32_t miny, uint32_t w, int gx, uint32_t dbits, uint32_t idx)
+__device__ __forceinline__ void gsr_emit(uint32_t* keys, uint32_t* vals, uint32_t off, uint32_t k, uint32_t minx,
+                                         uint32_t miny, uint32_t w, uint32_t gx, uint32_t idx)
 {
-	const uint32_t y = miny + k / w, x = minx + k % w;  // y outer, x inner (rasterizer_impl.cu:107-118)
-	uint64_t key = (uint64_t)(y * (uint32_t)gx + x);
-	key <<= 32;
-	key |= dbits;
-	keys[off + k] = key;
+	const uint32_t y = miny + k / w, x = minx + k % w;
+	keys[off + k] = y * gx + x;
 	vals[off + k] = idx;
 }
 
-__global__ void __launch_bounds__(256) gsr_duplicate_keys_kernel(GsrGeometry g, int P, int gx, uint64_t* keys, uint32_t* vals)
+__global__ void __launch_bounds__(GSR_PREPROCESS_BLOCK) gsr_duplicate_keys_kernel(GsrGeometry g, int P, uint32_t gx,
+                                                                                 uint32_t* __restrict__ keys,
+                                                                                 uint32_t* __restrict__ vals)
 {
-	const int idx = blockIdx.x * 256 + threadIdx.x;
-	uint32_t tiles = 0, off = 0, minx = 0, miny = 0, w = 1, dbits = 0;
-	if (idx < P) {
+	__shared__ uint32_t lds[GSR_PREPROCESS_BLOCK / 64];
+	const int i = blockIdx.x * GSR_PREPROCESS_BLOCK + threadIdx.x;
+	uint32_t idx = 0, tiles = 0, minx = 0, miny = 0, w = 1;
+	if (i < P) {
+		idx = g.perm[i];
 		tiles = g.tiles_touched[idx];
-		if (tiles) {
-			const GsrSplat& sp = g.splat[idx];
-			off = sp.slot_base;
-			minx = sp.rect_min & 0xffffu; miny = sp.rect_min >> 16;
-			w = sp.rect_wh & 0xffffu;
-			dbits = __float_as_uint(g.depths[idx]);
-		}
+	}
+	uint32_t total;
+	const uint32_t incl = gsr_block_incl_scan<GSR_PREPROCESS_BLOCK>(tiles, &total, lds) + g.sorted_block_sums[blockIdx.x];
+	const uint32_t off = incl - tiles;
+	if (tiles) {
+		GsrSplat* sp = g.splat + idx;
+		sp->slot_base = off;
+		const uint32_t rmin = sp->rect_min, rwh = sp->rect_wh;
+		minx = rmin & 0xffffu; miny = rmin >> 16;
+		w = rwh & 0xffffu;
 	}
 	if (tiles && tiles <= GSR_DUP_COOP)
-		for (uint32_t k = 0; k < tiles; k++) gsr_emit(keys, vals, off, k, minx, miny, w, gx, dbits, (uint32_t)idx);
+		for (uint32_t k = 0; k < tiles; k++) gsr_emit(keys, vals, off, k, minx, miny, w, gx, idx);
 
 	unsigned long long big = __ballot(tiles > GSR_DUP_COOP);
 	const int lane = threadIdx.x & 63;
@@ -122,50 +130,27 @@ __global__ void __launch_bounds__(256) gsr_duplicate_keys_kernel(GsrGeometry g, 
 		big &= big - 1;
 		const uint32_t s_tiles = __shfl(tiles, src, 64), s_off = __shfl(off, src, 64);
 		const uint32_t s_minx = __shfl(minx, src, 64), s_miny = __shfl(miny, src, 64), s_w = __shfl(w, src, 64);
-		const uint32_t s_d = __shfl(dbits, src, 64);
-		const uint32_t s_idx = (uint32_t)(idx - lane + src);
-		for (uint32_t k = lane; k < s_tiles; k += 64) gsr_emit(keys, vals, s_off, k, s_minx, s_miny, s_w, gx, s_d, s_idx);
+		const uint32_t s_idx = __shfl(idx, src, 64);
+		for (uint32_t k = lane; k < s_tiles; k += 64) gsr_emit(keys, vals, s_off, k, s_minx, s_miny, s_w, gx, s_idx);
 	}
 }
 
-void gsr_launch_duplicate_keys(GsrGeometry g, const int* radii, int P, int W, int H, GsrBinning b, hipStream_t s)
+void gsr_launch_duplicate_keys(GsrGeometry g, int P, int W, uint32_t* keys, uint32_t* vals, hipStream_t s)
 {
-	(void)radii; (void)H;
-	hipLaunchKernelGGL(gsr_duplicate_keys_kernel, dim3((P + 255) / 256), dim3(256), 0, s, g, P, gsr_grid_x(W),
-	                   b.keys_unsorted, b.point_list_unsorted);
+	const int nb = (P + GSR_PREPROCESS_BLOCK - 1) / GSR_PREPROCESS_BLOCK;
+	hipLaunchKernelGGL(gsr_duplicate_keys_kernel, dim3(nb), dim3(GSR_PREPROCESS_BLOCK), 0, s, g, P, (uint32_t)gsr_grid_x(W),
+	                   keys, vals);
 }
 
-// ---- sort ----------------------------------------------------------------------------------
-size_t gsr_sort_temp_bytes(int64_t R)
-{
-	if (R <= 0) return 0;
-	size_t bytes = 0;
-	hipError_t e = rocprim::radix_sort_pairs(nullptr, bytes, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr,
-	                                         (uint32_t*)nullptr, (size_t)R, 0u, 64u, (hipStream_t)0, false);
-	if (e != hipSuccess) {
-		(void)hipGetLastError();
-		return 0;
-	}
-	return bytes;
-}
-
-int gsr_sort_pairs(GsrBinning b, int64_t R, int end_bit, hipStream_t s)
-{
-	size_t bytes = b.sort_temp_bytes;
-	hipError_t e = rocprim::radix_sort_pairs(b.sort_temp, bytes, b.keys_unsorted, b.keys, b.point_list_unsorted,
-	                                         b.point_list, (size_t)R, 0u, (unsigned)end_bit, s, false);
-	return gsr_check_hip(e, "rocprim::radix_sort_pairs");
-}
-
-// ---- tile ranges (rasterizer_impl.cu:133-159; ranges zeroed by the caller, :377) --------------
-__global__ void __launch_bounds__(256) gsr_tile_ranges_kernel(const uint64_t* keys, int64_t L, uint2* ranges)
+// ---- tile ranges (rasterizer_impl.cu:133-159; ranges zeroed first, :377) -------------------------
+__global__ void __launch_bounds__(256) gsr_tile_ranges_kernel(const uint32_t* __restrict__ tile_keys, int64_t L, uint2* ranges)
 {
 	const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
 	if (idx >= L) return;
-	const uint32_t currtile = (uint32_t)(keys[idx] >> 32);
+	const uint32_t currtile = tile_keys[idx];
 	if (idx == 0) ranges[currtile].x = 0;
 	else {
-		const uint32_t prevtile = (uint32_t)(keys[idx - 1] >> 32);
+		const uint32_t prevtile = tile_keys[idx - 1];
 		if (currtile != prevtile) {
 			ranges[prevtile].y = (uint32_t)idx;
 			ranges[currtile].x = (uint32_t)idx;
@@ -174,9 +159,9 @@ __global__ void __launch_bounds__(256) gsr_tile_ranges_kernel(const uint64_t* ke
 	if (idx == L - 1) ranges[currtile].y = (uint32_t)L;
 }
 
-void gsr_launch_tile_ranges(const uint64_t* keys, int64_t R, uint2* ranges, int ntiles, hipStream_t s)
+void gsr_launch_tile_ranges(const uint32_t* tile_keys, int64_t R, uint2* ranges, int ntiles, hipStream_t s)
 {
 	(void)hipMemsetAsync(ranges, 0, (size_t)ntiles * sizeof(uint2), s);
 	if (R > 0)
-		hipLaunchKernelGGL(gsr_tile_ranges_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, s, keys, R, ranges);
+		hipLaunchKernelGGL(gsr_tile_ranges_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, s, tile_keys, R, ranges);
 }

@@ -16,12 +16,16 @@ static inline int gsr_grid_y(int H) { return (H + GSR_TILE_Y - 1) / GSR_TILE_Y; 
 // Typed views of the opaque blobs (offsets published through gsr_*_layout_of()).
 struct GsrGeometry {
 	GsrSplat* splat;
-	float* depths;
+	uint32_t* depth_keys;      // depth bits per Gaussian (0xFFFFFFFF = culled); after the depth sort: sorted keys
+	uint32_t* depth_keys_alt;  // ping-pong partner
+	uint32_t* perm;            // identity; after the depth sort: Gaussian ids in (depth, id) order
+	uint32_t* perm_alt;
 	uint32_t* tiles_touched;
-	uint32_t* point_offsets;
 	uint8_t* clamped;
-	uint32_t* status;       // [0] prefiltered trap, [1] num_rendered
-	uint32_t* block_sums;   // scan temp: per-preprocess-block tile counts, then exclusive offsets
+	uint32_t* status;             // [0] prefiltered trap, [1] num_rendered
+	uint32_t* block_sums;         // per-workgroup tile counts in original order (only their total is used)
+	uint32_t* sorted_block_sums;  // per-workgroup tile counts in depth order -> exclusive offsets
+	void* sort_table;             // radix histogram table for the P-sized depth sort
 };
 
 struct GsrImage {
@@ -32,12 +36,11 @@ struct GsrImage {
 };
 
 struct GsrBinning {
-	uint32_t* point_list;
-	uint32_t* point_list_unsorted;
-	uint64_t* keys;
-	uint64_t* keys_unsorted;
-	void* sort_temp;
-	size_t sort_temp_bytes;
+	uint32_t* point_list;      // sorted Gaussian ids (final)
+	uint32_t* point_list_alt;  // ping-pong partner
+	uint32_t* tile_keys;       // sorted tile ids (final)
+	uint32_t* tile_keys_alt;
+	void* sort_table;          // radix histogram table for the R-sized tile sort
 };
 
 GsrGeometry gsr_geometry_view(void* blob, int P);
@@ -84,12 +87,16 @@ void gsr_launch_preprocess(const GsrPreprocessArgs& a, hipStream_t s);
 void gsr_launch_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8_t* present, hipStream_t s);
 
 // binning.hip
-void gsr_launch_scan_block_sums(GsrGeometry g, int P, hipStream_t s);         // block_sums -> exclusive, total -> status[1]
-void gsr_launch_finalize_offsets(GsrGeometry g, int P, hipStream_t s);        // point_offsets (inclusive) + splat.slot_base
-void gsr_launch_duplicate_keys(GsrGeometry g, const int* radii, int P, int W, int H, GsrBinning b, hipStream_t s);
-int gsr_sort_pairs(GsrBinning b, int64_t R, int end_bit, hipStream_t s);
-size_t gsr_sort_temp_bytes(int64_t R);
-void gsr_launch_tile_ranges(const uint64_t* keys, int64_t R, uint2* ranges, int ntiles, hipStream_t s);
+void gsr_launch_scan_block_sums(uint32_t* block_sums, int nb, uint32_t* total_out, hipStream_t s);
+void gsr_launch_sorted_block_sums(GsrGeometry g, int P, hipStream_t s);
+void gsr_launch_duplicate_keys(GsrGeometry g, int P, int W, uint32_t* keys, uint32_t* vals, hipStream_t s);
+void gsr_launch_tile_ranges(const uint32_t* tile_keys, int64_t R, uint2* ranges, int ntiles, hipStream_t s);
+
+// sort.hip
+int gsr_radix_num_passes(int nbits_total);
+size_t gsr_radix_table_bytes(size_t n);
+void gsr_radix_sort_u32(uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v1, size_t n, int nbits_total, void* table_mem,
+                        int* result_in_first, hipStream_t s);
 
 // render_forward.hip
 void gsr_launch_render_forward(int W, int H, GsrImage img, const uint32_t* point_list, const GsrSplat* splat,

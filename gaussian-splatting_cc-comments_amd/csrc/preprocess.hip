@@ -38,6 +38,7 @@ __global__ void __launch_bounds__(GSR_PREPROCESS_BLOCK) gsr_preprocess_kernel(Gs
 	const int idx = blockIdx.x * GSR_PREPROCESS_BLOCK + threadIdx.x;
 	uint32_t tiles = 0;
 	int radius_out = 0;
+	uint32_t depth_key = 0xFFFFFFFFu;  // culled Gaussians sort behind every visible one
 	const int gx = (a.W + GSR_TILE_X - 1) / GSR_TILE_X, gy = (a.H + GSR_TILE_Y - 1) / GSR_TILE_Y;
 
 	if (idx < a.P) {
@@ -99,7 +100,7 @@ __global__ void __launch_bounds__(GSR_PREPROCESS_BLOCK) gsr_preprocess_kernel(Gs
 			}
 			tiles = (uint32_t)((maxy - miny) * (maxx - minx));
 			radius_out = gsr_f2i(my_radius);
-			a.g.depths[idx] = p_view.z;
+			depth_key = __float_as_uint(p_view.z);  // > 0.2, so unsigned order == float order
 			a.g.clamped[idx] = clamp_bits;
 			float4* rec = reinterpret_cast<float4*>(a.g.splat + idx);
 			rec[0] = make_float4(pix, piy, conic_a, conic_b);
@@ -110,6 +111,8 @@ __global__ void __launch_bounds__(GSR_PREPROCESS_BLOCK) gsr_preprocess_kernel(Gs
 		} while (0);
 		a.radii[idx] = radius_out;
 		a.g.tiles_touched[idx] = tiles;
+		a.g.depth_keys[idx] = depth_key;  // inputs of the depth sort (sort.hip)
+		a.g.perm[idx] = (uint32_t)idx;
 	}
 
 	// workgroup sum of tiles_touched -> block_sums[blockIdx.x]

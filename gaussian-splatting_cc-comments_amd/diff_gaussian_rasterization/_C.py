@@ -30,8 +30,8 @@ _sz = ctypes.c_size_t
 
 
 class GeometryLayout(ctypes.Structure):
-    _fields_ = [(n, _sz) for n in ("splat", "depths", "tiles_touched", "point_offsets", "clamped", "status",
-                                   "scan_temp", "total")]
+    _fields_ = [(n, _sz) for n in ("splat", "depth_keys", "depth_keys_alt", "perm", "perm_alt", "tiles_touched",
+                                   "clamped", "status", "scan_temp", "sort_table", "total")]
 
 
 class ImageLayout(ctypes.Structure):
@@ -39,8 +39,8 @@ class ImageLayout(ctypes.Structure):
 
 
 class BinningLayout(ctypes.Structure):
-    _fields_ = [(n, _sz) for n in ("point_list", "point_list_unsorted", "keys", "keys_unsorted", "sort_temp",
-                                   "sort_temp_bytes", "total")]
+    _fields_ = [(n, _sz) for n in ("point_list", "point_list_alt", "tile_keys", "tile_keys_alt", "sort_table",
+                                   "total")]
 
 
 class KernelTime(ctypes.Structure):

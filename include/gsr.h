@@ -55,13 +55,16 @@ size_t gsr_backward_scratch_bytes(int P, int64_t num_rendered);
 
 /* Byte offsets of the typed arrays inside each blob (introspection for tests / debuggers). */
 typedef struct {
-	size_t splat;          /* [P] 48-byte records: xy(2f) conic+opacity(4f) rgb(3f) slot_base(u32) rect_min(u16x2) rect_w(u32) */
-	size_t depths;         /* [P] f32 view-space z */
+	size_t splat;          /* [P] 48-byte records: xy(2f) conic+opacity(4f) rgb(3f) slot_base(u32) rect_min(u16x2) rect_wh(u16x2) */
+	size_t depth_keys;     /* [P] u32: after the call, depth bits sorted ascending (culled = 0xFFFFFFFF last) */
+	size_t depth_keys_alt; /* [P] u32 sort ping-pong */
+	size_t perm;           /* [P] u32 Gaussian ids in (depth, id) order */
+	size_t perm_alt;       /* [P] u32 sort ping-pong */
 	size_t tiles_touched;  /* [P] u32 */
-	size_t point_offsets;  /* [P] u32 inclusive prefix sum of tiles_touched */
 	size_t clamped;        /* [P] u8 bit c set = colour channel c was clamped at 0 */
-	size_t status;         /* [4] u32 device status words (word 0: prefiltered trap) */
-	size_t scan_temp;      /* prefix-sum temp storage */
+	size_t status;         /* [4] u32 device status words (0: prefiltered trap, 1: num_rendered) */
+	size_t scan_temp;      /* per-workgroup tile counts: original order, then depth order */
+	size_t sort_table;     /* radix histogram table of the depth sort */
 	size_t total;
 } gsr_geometry_layout;
 
@@ -74,12 +77,11 @@ typedef struct {
 } gsr_image_layout;
 
 typedef struct {
-	size_t point_list;          /* [R] u32 sorted Gaussian ids */
-	size_t point_list_unsorted; /* [R] u32 */
-	size_t keys;                /* [R] u64 sorted tile|depth keys */
-	size_t keys_unsorted;       /* [R] u64 */
-	size_t sort_temp;
-	size_t sort_temp_bytes;
+	size_t point_list;     /* [R] u32 Gaussian ids sorted by (tile, depth, id) -- the reference's point_list */
+	size_t point_list_alt; /* [R] u32 sort ping-pong */
+	size_t tile_keys;      /* [R] u32 tile id of each sorted instance (the high word of the reference's key) */
+	size_t tile_keys_alt;  /* [R] u32 sort ping-pong */
+	size_t sort_table;     /* radix histogram table of the tile sort */
 	size_t total;
 } gsr_binning_layout;
 
@@ -88,10 +90,12 @@ int gsr_image_layout_of(int width, int height, gsr_image_layout* out);
 int gsr_binning_layout_of(int P, int64_t num_rendered, int width, int height, gsr_binning_layout* out);
 
 /*
- * Forward, stage 1 of 2: per-Gaussian preprocess + tile-count prefix sum + read-back of the
- * instance count.  Replaces the first half of CudaRasterizer::Rasterizer::forward
- * (cuda_rasterizer/rasterizer_impl.cu:227-331: FORWARD::preprocess, cub InclusiveSum, the blocking
- * cudaMemcpy of num_rendered).  Blocks until `*num_rendered_host` is valid.
+ * Forward, stage 1 of 2: per-Gaussian preprocess, instance count and its read-back, and the
+ * per-Gaussian half of the sort (depth order of the Gaussians + their slot offsets), which keeps
+ * running on the stream while the host already has the count.  Replaces the first half of
+ * CudaRasterizer::Rasterizer::forward (cuda_rasterizer/rasterizer_impl.cu:227-331:
+ * FORWARD::preprocess, cub InclusiveSum, the blocking cudaMemcpy of num_rendered).  Blocks only
+ * until `*num_rendered_host` is valid.
  *   radii [P] int32 out (0 for culled Gaussians); geometry: gsr_geometry_bytes(P) bytes.
  */
 int gsr_forward_preprocess(
@@ -116,9 +120,10 @@ int gsr_forward_preprocess(
 	void* stream, int debug);
 
 /*
- * Forward, stage 2 of 2: key duplication, tile|depth sort, tile ranges, per-tile blend.
- * Replaces rasterizer_impl.cu:333-410 (duplicateWithKeys, cub SortPairs on bits [0,32+bit),
- * identifyTileRanges, FORWARD::render).  binning: gsr_binning_bytes(P, num_rendered, w, h) bytes;
+ * Forward, stage 2 of 2: (tile, Gaussian) instance emission in depth order, stable sort by tile,
+ * tile ranges, per-tile blend.  Replaces rasterizer_impl.cu:333-410 (duplicateWithKeys, cub
+ * SortPairs on bits [0,32+bit), identifyTileRanges, FORWARD::render); the sorted instance list
+ * and the ranges are identical to the reference's.  binning: gsr_binning_bytes(P, num_rendered, w, h) bytes;
  * image: gsr_image_bytes(w, h) bytes; out_color [3][H][W] fully written (background where empty).
  */
 int gsr_forward_render(

@@ -113,17 +113,26 @@ def unpack_state(cap, P, W, H):
     o["means2D"] = splat[:, 0:2]
     o["conic_opacity"] = splat[:, 2:6]
     o["rgb"] = splat[:, 6:9]
-    o["depths"] = geom[gl.depths:gl.depths + 4 * P].view(np.float32)
     o["tiles_touched"] = geom[gl.tiles_touched:gl.tiles_touched + 4 * P].view(np.uint32)
-    o["point_offsets"] = geom[gl.point_offsets:gl.point_offsets + 4 * P].view(np.uint32)
     o["clamped_bits"] = geom[gl.clamped:gl.clamped + P]
+    # depth sort outputs: Gaussian ids in (depth, id) order and their sorted depth bits
+    perm = geom[gl.perm:gl.perm + 4 * P].view(np.uint32)
+    skeys = geom[gl.depth_keys:gl.depth_keys + 4 * P].view(np.uint32)
+    o["perm"], o["sorted_depth_keys"] = perm, skeys
+    depth_bits = np.empty(P, np.uint32)
+    depth_bits[perm] = skeys
+    o["depth_bits"] = depth_bits                      # per Gaussian; 0xFFFFFFFF = culled
+    o["depths"] = depth_bits.view(np.float32)
+    o["slot_base"] = splat[:, 9].view(np.uint32)
     o["final_T"] = img[il.final_T:il.final_T + 4 * N].view(np.float32)
     o["n_contrib"] = img[il.n_contrib:il.n_contrib + 4 * N].view(np.uint32)
     o["ranges"] = img[il.ranges:il.ranges + 8 * T].view(np.uint32).reshape(T, 2)
     if R > 0:
         bl = _C.binning_layout(P, R, W, H)
         o["point_list"] = binning[bl.point_list:bl.point_list + 4 * R].view(np.uint32)
-        o["keys"] = binning[bl.keys:bl.keys + 8 * R].view(np.uint64)
+        o["tile_keys"] = binning[bl.tile_keys:bl.tile_keys + 4 * R].view(np.uint32)
+        # the reference's 64-bit key of every sorted instance: tile id << 32 | depth bits
+        o["keys"] = (o["tile_keys"].astype(np.uint64) << np.uint64(32)) | depth_bits[o["point_list"]].astype(np.uint64)
     return o
 
 
