@@ -120,33 +120,83 @@ __device__ __forceinline__ void gsr_cov3d_backward(const float* scale, float mod
 #undef Dm
 }
 
-__global__ void __launch_bounds__(256) gsr_gaussian_backward_kernel(GsrGaussianBackwardArgs a)
-{
-	const int idx = blockIdx.x * 256 + threadIdx.x;
-	if (idx >= a.P) return;
-	const int M = a.M;
+// Fixed-order sum of one Gaussian's contiguous run of per-tile gradient slots.  Runs of up to
+// GSR_SLOT_COOP slots are added by the owning lane; longer runs (a big splat can own > 1000) are
+// added by the whole wave, lanes striding over the run, then reduced with DPP -- so the wave's
+// time no longer follows its single most-loaded lane.  The order is fixed: bitwise reproducible.
+#define GSR_SLOT_COOP 12
+#define GSR_NACC 9
 
-	float dmean2D[3] = {0.f, 0.f, 0.f}, dconic[4] = {0.f, 0.f, 0.f, 0.f}, dop = 0.f, dcolor[3] = {0.f, 0.f, 0.f};
+__device__ __forceinline__ void gsr_add_slot(const GsrGradSlot* __restrict__ slots, const uint8_t* __restrict__ valid,
+                                             uint32_t s, float* acc)
+{
+	if (!valid[s]) return;
+	const float4* sl = reinterpret_cast<const float4*>(slots + s);
+	const float4 s0 = sl[0], s1 = sl[1];
+	const float s2 = sl[2].x;
+	acc[0] += s0.x; acc[1] += s0.y; acc[2] += s0.z; acc[3] += s0.w; acc[4] += s1.x;
+	acc[5] += s1.y; acc[6] += s1.z; acc[7] += s1.w; acc[8] += s2;
+}
+
+#define GSR_SH_ROW4 13  // LDS row stride in float4: 12 used + 1 pad -> conflict-free ds_read/write_b128 per row
+
+__global__ void __launch_bounds__(256) gsr_gaussian_backward_kernel(GsrGaussianBackwardArgs a, int sh_via_lds)
+{
+	__shared__ float4 s_sh[4][64 * GSR_SH_ROW4];
+	const int idx = blockIdx.x * 256 + threadIdx.x;
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const int M = a.M;
+	const bool in_range = idx < a.P;
+	const bool visible = in_range && a.radii[idx] > 0;
+	const int wave_first = blockIdx.x * 256 + wave * 64;
+	const int nrows = min(64, a.P - wave_first);  // Gaussians of this wave (<= 0: none)
+
+	// ---- stage the wave's SH block (64 x 48 floats, contiguous in HBM) into LDS, coalesced ----
+	if (sh_via_lds && nrows > 0) {
+		const float4* src = reinterpret_cast<const float4*>(a.shs + (size_t)wave_first * 48);
+#pragma unroll
+		for (int it = 0; it < 12; it++) {
+			const int f = it * 64 + lane;
+			if (f < nrows * 12) s_sh[wave][(f / 12) * GSR_SH_ROW4 + (f % 12)] = src[f];
+		}
+	}
+
+	// ---- fixed-order sum of this Gaussian's (Gaussian,tile) slots ----
+	float acc[GSR_NACC];
+#pragma unroll
+	for (int i = 0; i < GSR_NACC; i++) acc[i] = 0.f;
+	uint32_t tiles = 0, base = 0;
+	if (visible) {
+		tiles = a.g.tiles_touched[idx];
+		base = a.g.splat[idx].slot_base;
+	}
+	if (tiles <= GSR_SLOT_COOP)
+		for (uint32_t k = 0; k < tiles; k++) gsr_add_slot(a.slots, a.slot_valid, base + k, acc);
+	unsigned long long big = __ballot(tiles > GSR_SLOT_COOP);
+	while (big) {  // wave-uniform
+		const int src = __ffsll((long long)big) - 1;
+		big &= big - 1;
+		const uint32_t s_tiles = __shfl(tiles, src, 64), s_base = __shfl(base, src, 64);
+		float part[GSR_NACC];
+#pragma unroll
+		for (int i = 0; i < GSR_NACC; i++) part[i] = 0.f;
+		for (uint32_t k = lane; k < s_tiles; k += 64) gsr_add_slot(a.slots, a.slot_valid, s_base + k, part);
+#pragma unroll
+		for (int i = 0; i < GSR_NACC; i++) {
+			const float tot = __shfl(gsr_wave_sum_to_lane63(part[i]), 63, 64);
+			if (lane == src) acc[i] = tot;
+		}
+	}
+	__builtin_amdgcn_wave_barrier();
+
+	float dmean2D[3] = {acc[0], acc[1], 0.f}, dconic[4] = {acc[2], acc[3], 0.f, acc[4]}, dop = acc[5];
+	float dcolor[3] = {acc[6], acc[7], acc[8]};
 	float dmean3D[3] = {0.f, 0.f, 0.f}, dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 	float dscale[3] = {0.f, 0.f, 0.f}, drot[4] = {0.f, 0.f, 0.f, 0.f};
-	float* dsh = a.dL_dsh ? a.dL_dsh + (size_t)idx * M * 3 : nullptr;
-	const bool visible = a.radii[idx] > 0;
+	float* dsh_global = (a.dL_dsh && in_range) ? a.dL_dsh + (size_t)idx * M * 3 : nullptr;
+	float* my_row = reinterpret_cast<float*>(&s_sh[wave][lane * GSR_SH_ROW4]);
 
 	if (visible) {
-		// ---- fixed-order sum of this Gaussian's (Gaussian,tile) slots ----
-		const uint32_t tiles = a.g.tiles_touched[idx];
-		const uint32_t base = a.g.splat[idx].slot_base;
-		for (uint32_t k = 0; k < tiles; k++) {
-			if (!a.slot_valid[base + k]) continue;
-			const float4* sl = reinterpret_cast<const float4*>(a.slots + base + k);
-			const float4 s0 = sl[0], s1 = sl[1];
-			const float s2 = sl[2].x;
-			dmean2D[0] += s0.x; dmean2D[1] += s0.y;
-			dconic[0] += s0.z; dconic[1] += s0.w; dconic[3] += s1.x;
-			dop += s1.y;
-			dcolor[0] += s1.z; dcolor[1] += s1.w; dcolor[2] += s2;
-		}
-
 		// ---- computeCov2DCUDA, backward.cu:144-277 ----
 		float cov3D[6];
 		float sc[3] = {0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
@@ -218,14 +268,43 @@ __global__ void __launch_bounds__(256) gsr_gaussian_backward_kernel(GsrGaussianB
 		dmean3D[1] += (proj[4] * m_w - proj[7] * mul1) * gx2 + (proj[5] * m_w - proj[7] * mul2) * gy2;
 		dmean3D[2] += (proj[8] * m_w - proj[11] * mul1) * gx2 + (proj[9] * m_w - proj[11] * mul2) * gy2;
 
-		if (a.shs)
-			gsr_sh_backward(a.D, M, mean, a.cam_pos, a.shs + (size_t)idx * M * 3, a.g.clamped[idx], dcolor, dmean3D, dsh);
+		if (a.shs) {
+			if (sh_via_lds) {
+				float shv[48];  // own row out of LDS into registers, then dL_dsh overwrites the row in place
+#pragma unroll
+				for (int j = 0; j < 12; j++) {
+					const float4 v = s_sh[wave][lane * GSR_SH_ROW4 + j];
+					shv[4 * j] = v.x; shv[4 * j + 1] = v.y; shv[4 * j + 2] = v.z; shv[4 * j + 3] = v.w;
+				}
+				gsr_sh_backward(a.D, M, mean, a.cam_pos, shv, a.g.clamped[idx], dcolor, dmean3D, my_row);
+			} else {
+				gsr_sh_backward(a.D, M, mean, a.cam_pos, a.shs + (size_t)idx * M * 3, a.g.clamped[idx], dcolor, dmean3D, dsh_global);
+			}
+		}
 		if (a.scales)
 			gsr_cov3d_backward(sc, a.scale_modifier, q, dcov, dscale, drot);
 	}
 
-	if ((!visible || !a.shs) && dsh)
-		for (int k = 0; k < M * 3; k++) dsh[k] = 0.f;
+	// ---- dL_dsh: zeros for culled Gaussians; coalesced write-out of the wave's block ----
+	if (sh_via_lds) {
+		if (!visible) {
+#pragma unroll
+			for (int j = 0; j < 12; j++) s_sh[wave][lane * GSR_SH_ROW4 + j] = make_float4(0.f, 0.f, 0.f, 0.f);
+		}
+		__builtin_amdgcn_wave_barrier();
+		if (nrows > 0) {
+			float4* dst = reinterpret_cast<float4*>(a.dL_dsh + (size_t)wave_first * 48);
+#pragma unroll
+			for (int it = 0; it < 12; it++) {
+				const int f = it * 64 + lane;
+				if (f < nrows * 12) dst[f] = s_sh[wave][(f / 12) * GSR_SH_ROW4 + (f % 12)];
+			}
+		}
+	} else if ((!visible || !a.shs) && dsh_global) {
+		for (int k = 0; k < M * 3; k++) dsh_global[k] = 0.f;
+	}
+
+	if (!in_range) return;
 #pragma unroll
 	for (int k = 0; k < 3; k++) {
 		a.dL_dmean2D[3 * (size_t)idx + k] = dmean2D[k];
@@ -245,5 +324,7 @@ __global__ void __launch_bounds__(256) gsr_gaussian_backward_kernel(GsrGaussianB
 
 void gsr_launch_gaussian_backward(const GsrGaussianBackwardArgs& a, hipStream_t s)
 {
-	hipLaunchKernelGGL(gsr_gaussian_backward_kernel, dim3((a.P + 255) / 256), dim3(256), 0, s, a);
+	// LDS-transposed SH path: the flagship layout (16 coefficients) with 16-byte aligned tensors
+	const int sh_via_lds = (a.shs && a.dL_dsh && a.M == 16 && (((uintptr_t)a.shs | (uintptr_t)a.dL_dsh) & 15u) == 0) ? 1 : 0;
+	hipLaunchKernelGGL(gsr_gaussian_backward_kernel, dim3((a.P + 255) / 256), dim3(256), 0, s, a, sh_via_lds);
 }
