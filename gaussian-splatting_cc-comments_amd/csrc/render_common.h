@@ -49,3 +49,69 @@ __device__ __forceinline__ int gsr_mbcnt(unsigned long long mask)
 {
 	return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
 }
+
+// ---- the (pixel, Gaussian) pair, evaluated identically by the forward and the backward kernel ----
+// power = -0.5f * (a*dx*dx + c*dy*dy) - b*dx*dy (forward.cu:437, backward.cu:518) is evaluated in
+// EXACTLY that operation order with no FMA contraction.  For elongated splats the three terms are
+// O(1000) and cancel to O(1), so G = exp(power) carries a relative rounding error of up to ~1e-4
+// whose value depends on the operation order; only the reference's own order reproduces the
+// reference's numbers (measured: a contracted / base-2 form moved whole-Gaussian gradients by
+// 1.2e-5 relative).  ax2 = (a*dx)*dx and bdx = b*dx are shared by the lane's four pixels.
+// Forward and backward run the same instruction sequence on the same staged numbers, so their
+// accept/reject decisions agree bit for bit (the backward undoes exactly the products the
+// forward formed).
+__device__ __forceinline__ float gsr_pair_power(float ax2, float bdx, float c, float dy)
+{
+	const float cy2 = __fmul_rn(__fmul_rn(c, dy), dy);
+	return __fsub_rn(__fmul_rn(-0.5f, __fadd_rn(ax2, cy2)), __fmul_rn(bdx, dy));
+}
+
+// ---- wave64 butterfly reduction of 8 values (gfx950 v_permlane{32,16}_swap + DPP) ----------------
+// Each fold halves the number of live registers instead of reducing every register over all 64
+// lanes: 8 values cost 18 cross-lane ops instead of 48.  On return every lane of the 8-lane group g
+// (lanes 8g .. 8g+7) holds the wave total of value gsr_bfly_index(g).
+// Inline asm, not __builtin_amdgcn_permlane{32,16}_swap: with ROCm 7.2's hipcc the sum r[0] + r[1] of
+// the builtin's two results is emitted as vdst + vdst (second result dropped; verified with
+// tools/bfly_probe.hip on gfx950).  The leading s_nop 1 is the wait the compiler itself places
+// between a VALU write of an operand and the swap.
+__device__ __forceinline__ float gsr_fold32(float a, float b)
+{
+	// swaps a[32..63] with b[0..31]; the sum is a folded over the halves in lanes < 32, b in lanes >= 32
+	asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+	return a + b;
+}
+
+__device__ __forceinline__ float gsr_fold16(float a, float b)
+{
+	// swaps the odd 16-lane rows of a with the even rows of b; rows of the sum: a(r0+r1) b(r0+r1) a(r2+r3) b(r2+r3)
+	asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+	return a + b;
+}
+
+__device__ __forceinline__ float gsr_fold8(float a, float b, bool upper_half_row)
+{
+	const float keep = upper_half_row ? b : a, send = upper_half_row ? a : b;
+	return keep + gsr_dpp_mov<0x128, 0xF, 0xF, true>(send);  // row_ror:8 = partner in the other half row
+}
+
+__device__ __forceinline__ float gsr_sum8(float v)
+{
+	v += gsr_dpp_mov<0xB1, 0xF, 0xF, true>(v);   // quad_perm [1,0,3,2]
+	v += gsr_dpp_mov<0x4E, 0xF, 0xF, true>(v);   // quad_perm [2,3,0,1]
+	v += gsr_dpp_mov<0x141, 0xF, 0xF, true>(v);  // row_half_mirror
+	return v;
+}
+
+// value index held by 8-lane group g after gsr_bfly8()
+__device__ __forceinline__ int gsr_bfly_index(int g)
+{
+	return ((g & 1) << 2) | (g & 2) | ((g >> 2) & 1);  // {0,4,2,6,1,5,3,7}
+}
+
+__device__ __forceinline__ float gsr_bfly8(const float* v, int lane)
+{
+	const float w0 = gsr_fold32(v[0], v[1]), w1 = gsr_fold32(v[2], v[3]);
+	const float w2 = gsr_fold32(v[4], v[5]), w3 = gsr_fold32(v[6], v[7]);
+	const float u0 = gsr_fold16(w0, w1), u1 = gsr_fold16(w2, w3);
+	return gsr_sum8(gsr_fold8(u0, u1, (lane & 8) != 0));
+}
