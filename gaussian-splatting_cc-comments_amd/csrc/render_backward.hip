@@ -16,7 +16,7 @@
 
 #define GSR_BWD_NV 9
 
-__global__ void __launch_bounds__(64 * GSR_WAVES_PER_WG) gsr_render_backward_wave_kernel(
+__global__ void __launch_bounds__(64 * GSR_WAVES_PER_WG, 4) gsr_render_backward_wave_kernel(
 	int W, int H, int gx, int ntiles, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
 	const GsrSplat* __restrict__ splat, const float* __restrict__ bg, const float* __restrict__ final_Ts,
 	const uint32_t* __restrict__ n_contrib, const uint32_t* __restrict__ tile_max_contrib,
@@ -41,27 +41,24 @@ __global__ void __launch_bounds__(64 * GSR_WAVES_PER_WG) gsr_render_backward_wav
 	const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
 	const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;
 
-	float T[GSR_PIX_PER_LANE], T_final[GSR_PIX_PER_LANE], pfy[GSR_PIX_PER_LANE], bgdot[GSR_PIX_PER_LANE];
-	float ac0[GSR_PIX_PER_LANE], ac1[GSR_PIX_PER_LANE], ac2[GSR_PIX_PER_LANE];
-	float lc0[GSR_PIX_PER_LANE], lc1[GSR_PIX_PER_LANE], lc2[GSR_PIX_PER_LANE], last_alpha[GSR_PIX_PER_LANE];
+	// per-pixel state, kept small (36 registers for 4 pixels) so that 4 waves fit per SIMD
+	float T[GSR_PIX_PER_LANE], tfb[GSR_PIX_PER_LANE];  // running T; -T_final * (bg . dL/dpix)
+	float ac0[GSR_PIX_PER_LANE], ac1[GSR_PIX_PER_LANE], ac2[GSR_PIX_PER_LANE];  // accum_rec as the NEXT hit will see it
 	float dp0[GSR_PIX_PER_LANE], dp1[GSR_PIX_PER_LANE], dp2[GSR_PIX_PER_LANE];
 	int last_contributor[GSR_PIX_PER_LANE];
+	const float pfy0 = (float)py0;
 #pragma unroll
 	for (int k = 0; k < GSR_PIX_PER_LANE; k++) {
 		const int py = py0 + 4 * k;
 		const bool inside = px < W && py < H;
 		const uint32_t pix_id = inside ? (uint32_t)(W * py + px) : 0u;
-		pfy[k] = (float)py;
-		T_final[k] = inside ? final_Ts[pix_id] : 0.f;
-		T[k] = T_final[k];
+		T[k] = inside ? final_Ts[pix_id] : 0.f;
 		last_contributor[k] = inside ? (int)n_contrib[pix_id] : 0;
 		dp0[k] = inside ? dL_dpixels[pix_id] : 0.f;
 		dp1[k] = inside ? dL_dpixels[plane + pix_id] : 0.f;
 		dp2[k] = inside ? dL_dpixels[2 * plane + pix_id] : 0.f;
-		bgdot[k] = bg0 * dp0[k] + bg1 * dp1[k] + bg2 * dp2[k];
+		tfb[k] = -T[k] * (bg0 * dp0[k] + bg1 * dp1[k] + bg2 * dp2[k]);
 		ac0[k] = ac1[k] = ac2[k] = 0.f;
-		lc0[k] = lc1[k] = lc2[k] = 0.f;
-		last_alpha[k] = 0.f;
 	}
 
 	// back to front: batch position q = base + lane maps to range position n - 1 - q
@@ -74,7 +71,8 @@ __global__ void __launch_bounds__(64 * GSR_WAVES_PER_WG) gsr_render_backward_wav
 	const int out_index = gsr_bfly_index(lane >> 3);  // which of v[0..7] this lane's 8-lane group ends up holding
 
 	for (int base = 0; base < n; base += 64) {
-		const bool keep = (base + lane < n) && gsr_tile_may_hit(ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, x0f, y0f);
+		const uint32_t bands = (base + lane < n) ? gsr_tile_band_mask(ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, x0f, y0f) : 0u;
+		const bool keep = bands != 0u;
 		const unsigned long long mask = __ballot(keep);
 		const int cnt = __popcll(mask);
 		if (keep) {
@@ -83,7 +81,7 @@ __global__ void __launch_bounds__(64 * GSR_WAVES_PER_WG) gsr_render_backward_wav
 			const uint32_t slot = __float_as_uint(rc.y) + ((uint32_t)ty - (rmin >> 16)) * (rwh & 0xffffu) + ((uint32_t)tx - (rmin & 0xffffu));
 			rec[0][pos] = ra;
 			rec[1][pos] = rb;
-			rec[2][pos] = make_float4(rc.x, __int_as_float(n - 1 - (base + lane)), __uint_as_float(slot), 0.f);
+			rec[2][pos] = make_float4(rc.x, __int_as_float(n - 1 - (base + lane)), __uint_as_float(slot), __uint_as_float(bands));
 		}
 		if (base + 64 + lane < n) {
 			const float4* p = reinterpret_cast<const float4*>(splat + id_next);
@@ -95,62 +93,77 @@ __global__ void __launch_bounds__(64 * GSR_WAVES_PER_WG) gsr_render_backward_wav
 		for (int j = 0; j < cnt; j++) {
 			const float4 A = rec[0][j];   // x, y, conic a, conic b
 			const float4 B = rec[1][j];   // conic c, opacity, r, g
-			const float4 Cc = rec[2][j];  // b, position in the full range, slot
+			const float4 Cc = rec[2][j];  // b, position in the full range, slot, band mask
 			const int contributor = __float_as_int(Cc.y);  // backward.cu:511-515
+			const uint32_t bands = __builtin_amdgcn_readfirstlane(__float_as_uint(Cc.w));  // wave-uniform
 			const float dx = A.x - pfx;
 			const float ax2 = __fmul_rn(__fmul_rn(A.z, dx), dx), bdx = __fmul_rn(A.w, dx);
+			// per-lane partial sums over its four pixels.  The geometric terms are kept as raw moments
+			// of f = G * dL/dG (sum f dx, f dy, f dx^2, f dx dy, f dy^2); the conic and the 0.5*W / 0.5*H /
+			// -0.5 factors of backward.cu:574-594 are applied once per instance after the reduction.
 			float v[GSR_BWD_NV];
 #pragma unroll
 			for (int i = 0; i < GSR_BWD_NV; i++) v[i] = 0.f;
 			bool any = false;
 #pragma unroll
 			for (int k = 0; k < GSR_PIX_PER_LANE; k++) {
-				const float dy = A.y - pfy[k];
+				if (!(bands & (1u << k))) continue;  // this 16x4 band cannot be reached: scalar branch
+				const float dy = A.y - (pfy0 + 4.0f * k);  // pixel row as an exact small integer
 				const float power = gsr_pair_power(ax2, bdx, B.x, dy);
 				const float G = __expf(power);
 				const float alpha = fminf(0.99f, B.y * G);
 				const bool hit = contributor < last_contributor[k] && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
-				if (__ballot(hit) == 0ull) continue;  // wave-uniform: none of the 64 pixels of this row group
+				if (__ballot(hit) == 0ull) continue;  // wave-uniform
 				if (hit) {
 					any = true;
 					const float inv1ma = __builtin_amdgcn_rcpf(1.f - alpha);  // 1 ulp; exact IEEE division changed no parity figure
 					T[k] = T[k] * inv1ma;
 					const float dchannel_dcolor = alpha * T[k];
-					// accum_rec and (c - accum_rec) cancel heavily when neighbouring colours are close, so
-					// this recurrence and dot product keep the reference's exact operation order with no FMA
+					// accum_rec and (c - accum_rec) cancel heavily when neighbouring colours are close, so the
+					// recurrence and this dot product keep the reference's exact operation order with no FMA
 					// contraction (backward.cu:553-559); everything else may contract
-					const float la = last_alpha[k], oml = __fsub_rn(1.f, la);
-					ac0[k] = __fadd_rn(__fmul_rn(la, lc0[k]), __fmul_rn(oml, ac0[k]));
-					ac1[k] = __fadd_rn(__fmul_rn(la, lc1[k]), __fmul_rn(oml, ac1[k]));
-					ac2[k] = __fadd_rn(__fmul_rn(la, lc2[k]), __fmul_rn(oml, ac2[k]));
-					lc0[k] = B.z; lc1[k] = B.w; lc2[k] = Cc.x;
 					float dL_dalpha = __fadd_rn(__fadd_rn(__fmul_rn(__fsub_rn(B.z, ac0[k]), dp0[k]),
 					                                      __fmul_rn(__fsub_rn(B.w, ac1[k]), dp1[k])),
 					                            __fmul_rn(__fsub_rn(Cc.x, ac2[k]), dp2[k]));
-					v[6] += dchannel_dcolor * dp0[k];
-					v[7] += dchannel_dcolor * dp1[k];
-					v[8] += dchannel_dcolor * dp2[k];
+					// the reference updates accum_rec lazily at the NEXT hit from (last_alpha, last_color);
+					// doing it now uses the same operands and yields the same bits, without keeping them
+					const float oma = __fsub_rn(1.f, alpha);
+					ac0[k] = __fadd_rn(__fmul_rn(alpha, B.z), __fmul_rn(oma, ac0[k]));
+					ac1[k] = __fadd_rn(__fmul_rn(alpha, B.w), __fmul_rn(oma, ac1[k]));
+					ac2[k] = __fadd_rn(__fmul_rn(alpha, Cc.x), __fmul_rn(oma, ac2[k]));
+					// (this file is compiled with -ffp-contract=off; the accumulations below ask for FMA
+					// explicitly: one rounding instead of two, and no effect on the operation order)
+					v[6] = __builtin_fmaf(dchannel_dcolor, dp0[k], v[6]);
+					v[7] = __builtin_fmaf(dchannel_dcolor, dp1[k], v[7]);
+					v[8] = __builtin_fmaf(dchannel_dcolor, dp2[k], v[8]);
 					dL_dalpha *= T[k];
-					last_alpha[k] = alpha;
-					dL_dalpha += (-T_final[k] * inv1ma) * bgdot[k];
-					const float dL_dG = B.y * dL_dalpha;
-					const float gdx = G * dx, gdy = G * dy;
-					const float dG_ddelx = -gdx * A.z - gdy * A.w;
-					const float dG_ddely = -gdy * B.x - gdx * A.w;
-					v[0] += dL_dG * dG_ddelx * ddelx_dx;
-					v[1] += dL_dG * dG_ddely * ddely_dy;
-					v[2] += -0.5f * gdx * dx * dL_dG;
-					v[3] += -0.5f * gdx * dy * dL_dG;
-					v[4] += -0.5f * gdy * dy * dL_dG;
-					v[5] += G * dL_dalpha;
+					dL_dalpha += tfb[k] * inv1ma;
+					v[5] = __builtin_fmaf(G, dL_dalpha, v[5]);  // dL/dopacity
+					const float f = (B.y * dL_dalpha) * G;      // dL/dG * G
+					const float fdx = f * dx, fdy = f * dy;
+					v[0] += fdx;
+					v[1] += fdy;
+					v[2] = __builtin_fmaf(fdx, dx, v[2]);
+					v[3] = __builtin_fmaf(fdx, dy, v[3]);
+					v[4] = __builtin_fmaf(fdy, dy, v[4]);
 				}
 			}
 			if (__ballot(any)) {  // wave-uniform
 				const float t8 = gsr_bfly8(v, lane);           // group g holds the total of v[gsr_bfly_index(g)]
 				const float t9 = gsr_wave_sum_to_lane63(v[8]);  // lane 63 holds the total of v[8]
+				// totals of the five moments to the lanes that finish the formulas (group leaders)
+				// v[0] ends in group 0 (lane 0), v[1] in group 4 (lane 32): scalar broadcasts
+				const float sx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, t8), 0));
+				const float sy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, t8), 32));
 				const uint32_t slot = __float_as_uint(Cc.z);
 				float* out = reinterpret_cast<float*>(slots + slot);
-				if ((lane & 7) == 0) out[out_index] = t8;
+				if ((lane & 7) == 0) {
+					float r = t8;  // out_index 5 (opacity), 6, 7 (colour) are stored as they are
+					if (out_index == 0) r = -ddelx_dx * (A.z * sx + A.w * sy);       // dL/dmean2D.x
+					else if (out_index == 1) r = -ddely_dy * (B.x * sy + A.w * sx);  // dL/dmean2D.y
+					else if (out_index <= 4) r = -0.5f * t8;                         // dL/dconic .x .y .w
+					out[out_index] = r;
+				}
 				if (lane == 63) {
 					out[8] = t9;
 					slot_valid[slot] = 1;

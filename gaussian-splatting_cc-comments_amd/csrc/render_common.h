@@ -11,37 +11,43 @@
 #define GSR_WAVES_PER_WG 4
 #define GSR_PIX_PER_LANE 4
 
-// Conservative, exact-result-preserving tile culling.  alpha = o*exp(-q/2) with
-// q = a dx^2 + 2 b dx dy + c dy^2 can reach 1/255 inside the tile only if
-// min over the tile's pixel rectangle of q <= 2 ln(255 o).  The minimum of the convex quadratic
-// over the rectangle is 0 when the centre lies inside it and otherwise sits on one of the four
-// edges, where it has a closed form.  A slack of 1e-3 in q (5e-4 relative in alpha, four orders
-// of magnitude above fp32 rounding of `power`) keeps the test conservative, so an instance that
-// the reference would blend into any pixel of this tile is never dropped; dropped instances
-// contribute exactly nothing in the reference either (forward.cu:438-447, backward.cu:521-531).
-__device__ __forceinline__ bool gsr_tile_may_hit(float mx, float my, float a, float b, float c, float op, float x0,
-                                                 float y0)
+// Conservative, exact-result-preserving culling.  alpha = o*exp(-q/2) with
+// q = a dx^2 + 2 b dx dy + c dy^2 can reach 1/255 inside a pixel rectangle only if the minimum of
+// q over the rectangle is <= 2 ln(255 o).  The minimum of the convex quadratic over a rectangle is
+// 0 when the centre lies inside it and otherwise sits on one of the four edges, where it has a
+// closed form.  A slack of 1e-3 in q (5e-4 relative in alpha, orders of magnitude above the fp32
+// rounding of `power`) keeps the test conservative: an instance that the reference would blend
+// into any pixel of the rectangle is never dropped, and dropped instances contribute exactly
+// nothing in the reference either (forward.cu:438-447, backward.cu:521-531).
+// Returns a 4-bit mask: bit k set = the instance may reach the band of pixel rows 4k..4k+3 of the
+// 16x16 tile at (x0, y0) (the rows owned by pixel slot k of every lane); 0 = drop the instance.
+__device__ __forceinline__ uint32_t gsr_tile_band_mask(float mx, float my, float a, float b, float c, float op, float x0,
+                                                       float y0)
 {
+	if (!(a > 0.f) || !(c > 0.f) || !(a * c - b * b > 0.f)) return 0xFu;  // not positive definite: keep
 	const float thr = 2.0f * __logf(255.0f * op) + 1e-3f;
-	if (!(a > 0.f) || !(c > 0.f) || !(a * c - b * b > 0.f)) return true;  // not positive definite: keep
-	const float dxl = mx - (x0 + 15.0f), dxh = mx - x0;  // dx = mean.x - pixel.x over the tile
-	const float dyl = my - (y0 + 15.0f), dyh = my - y0;
-	if (dxl <= 0.f && dxh >= 0.f && dyl <= 0.f && dyh >= 0.f) return !(thr < 0.f);
-	float q = 3.0e38f;
+	if (thr < 0.f) return 0u;  // alpha < 1/255 even at the centre
+	const float dxl = mx - (x0 + 15.0f), dxh = mx - x0;  // dx = mean.x - pixel.x over the tile's columns
 	const float nbc = -b / c, nba = -b / a;
-	{
-		float X = dxl, Y = fminf(dyh, fmaxf(dyl, nbc * X));
-		q = fminf(q, a * X * X + 2.f * b * X * Y + c * Y * Y);
-		X = dxh; Y = fminf(dyh, fmaxf(dyl, nbc * X));
-		q = fminf(q, a * X * X + 2.f * b * X * Y + c * Y * Y);
+	const bool x_in = dxl <= 0.f && dxh >= 0.f;
+	uint32_t mask = 0u;
+#pragma unroll
+	for (int k = 0; k < 4; k++) {
+		const float dyl = my - (y0 + 4.0f * k + 3.0f), dyh = my - (y0 + 4.0f * k);
+		float q = 0.f;
+		if (!(x_in && dyl <= 0.f && dyh >= 0.f)) {
+			float X = dxl, Y = fminf(dyh, fmaxf(dyl, nbc * X));
+			q = a * X * X + 2.f * b * X * Y + c * Y * Y;
+			X = dxh; Y = fminf(dyh, fmaxf(dyl, nbc * X));
+			q = fminf(q, a * X * X + 2.f * b * X * Y + c * Y * Y);
+			Y = dyl; X = fminf(dxh, fmaxf(dxl, nba * Y));
+			q = fminf(q, a * X * X + 2.f * b * X * Y + c * Y * Y);
+			Y = dyh; X = fminf(dxh, fmaxf(dxl, nba * Y));
+			q = fminf(q, a * X * X + 2.f * b * X * Y + c * Y * Y);
+		}
+		if (!(q > thr)) mask |= 1u << k;  // NaN -> keep
 	}
-	{
-		float Y = dyl, X = fminf(dxh, fmaxf(dxl, nba * Y));
-		q = fminf(q, a * X * X + 2.f * b * X * Y + c * Y * Y);
-		Y = dyh; X = fminf(dxh, fmaxf(dxl, nba * Y));
-		q = fminf(q, a * X * X + 2.f * b * X * Y + c * Y * Y);
-	}
-	return !(q > thr);  // NaN -> keep
+	return mask;
 }
 
 // number of set bits of `mask` below this lane

@@ -6,7 +6,7 @@
 //
 // Decomposition (render_common.h): one wave64 per tile, four pixels per lane, no workgroup
 // barrier.  Per batch of 64 instances each lane gathers one 48-byte splat record (prefetched one
-// batch ahead, ids two batches ahead), tests it against the tile (gsr_tile_may_hit) and the
+// batch ahead, ids two batches ahead), tests it against the tile (gsr_tile_band_mask) and the
 // survivors are compacted into the wave's LDS slice; the inner loop broadcasts one record per
 // iteration to all lanes.  Skipped instances
 // are exactly those that blend into no pixel of the tile, so results are unchanged and
@@ -61,14 +61,15 @@ __global__ void __launch_bounds__(64 * GSR_WAVES_PER_WG) gsr_render_forward_wave
 
 	for (int base = 0; base < n; base += 64) {
 		if (__ballot(fmaxf(fmaxf(Trun[0], Trun[1]), fmaxf(Trun[2], Trun[3])) > 0.f) == 0ull) break;
-		const bool keep = (base + lane < n) && gsr_tile_may_hit(ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, x0f, y0f);
+		const uint32_t bands = (base + lane < n) ? gsr_tile_band_mask(ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, x0f, y0f) : 0u;
+		const bool keep = bands != 0u;
 		const unsigned long long mask = __ballot(keep);
 		const int cnt = __popcll(mask);
 		if (keep) {
 			const int pos = gsr_mbcnt(mask);
 			rec[0][pos] = ra;
 			rec[1][pos] = rb;
-			rec[2][pos] = make_float4(rc.x, __uint_as_float((uint32_t)(base + lane + 1)), 0.f, 0.f);
+			rec[2][pos] = make_float4(rc.x, __uint_as_float((uint32_t)(base + lane + 1)), __uint_as_float(bands), 0.f);
 		}
 		if (base + 64 + lane < n) {
 			const float4* p = reinterpret_cast<const float4*>(splat + id_next);
@@ -80,16 +81,20 @@ __global__ void __launch_bounds__(64 * GSR_WAVES_PER_WG) gsr_render_forward_wave
 		for (int j = 0; j < cnt; j++) {
 			const float4 A = rec[0][j];   // x, y, conic a, conic b
 			const float4 B = rec[1][j];   // conic c, opacity, r, g
-			const float4 Cc = rec[2][j];  // b, contributor
+			const float4 Cc = rec[2][j];  // b, contributor, band mask
 			const uint32_t contributor = __float_as_uint(Cc.y);
+			const uint32_t bands = __builtin_amdgcn_readfirstlane(__float_as_uint(Cc.z));  // wave-uniform
 			const float dx = A.x - pfx;
 			const float ax2 = __fmul_rn(__fmul_rn(A.z, dx), dx), bdx = __fmul_rn(A.w, dx);
 #pragma unroll
 			for (int k = 0; k < GSR_PIX_PER_LANE; k++) {
+				if (!(bands & (1u << k))) continue;  // this 16x4 band cannot be reached: scalar branch
 				const float dy = A.y - pfy[k];
 				const float power = gsr_pair_power(ax2, bdx, B.x, dy);
 				const float alpha = fminf(0.99f, B.y * __expf(power));
-				const float test_T = Trun[k] * (1.0f - alpha);
+				// (1 - alpha) is rounded BEFORE the product, as in forward.cu:449: the backward pass divides
+				// by that rounded value, so contracting this into fma(-T, alpha, T) would break the pairing
+				const float test_T = __fmul_rn(Trun[k], __fsub_rn(1.0f, alpha));
 				const bool live = !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
 				const bool pass = live && !(test_T < 0.0001f);  // Trun == 0 (done) can never pass
 				const float w = pass ? alpha * Trun[k] : 0.0f;

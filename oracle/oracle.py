@@ -165,6 +165,29 @@ def backward(s, dL_dpix, accum_mode=0):
     return g
 
 
+def blend_backward_exact(s, dL_dpix):
+    """The backward blend evaluated in float64 with the fp32 path's discrete decisions
+    (gsro_render_backward_exact).  Returns float64 dicts shaped like backward()'s blend outputs:
+    dL_dmeans2D (P,3), dL_dconic (P,2,2), dL_dopacity (P,1), dL_dcolors (P,3)."""
+    dL_dpix = _f32(dL_dpix)
+    P, W, H = s["P"], s["W"], s["H"]
+    m2 = np.zeros((P, 2), np.float64)
+    con = np.zeros((P, 3), np.float64)
+    op = np.zeros(P, np.float64)
+    col = np.zeros((P, 3), np.float64)
+    colors = s["colors_precomp"] if s["colors_precomp"] is not None else s["rgb"]
+    if P and s["num_rendered"]:
+        lib().gsro_render_backward_exact(W, H, _p(s["ranges"], _u), _p(s["point_list"], _u), _p(s["bg"], _f),
+                                         _p(s["means2D"], _f), _p(s["conic_opacity"], _f), _p(colors, _f),
+                                         _p(s["n_contrib"], _u), _p(dL_dpix, _f), _p(m2, _d), _p(con, _d), _p(op, _d),
+                                         _p(col, _d))
+    g = dict(dL_dmeans2D=np.zeros((P, 3)), dL_dconic=np.zeros((P, 2, 2)), dL_dopacity=op.reshape(P, 1), dL_dcolors=col)
+    g["dL_dmeans2D"][:, :2] = m2
+    c4 = g["dL_dconic"].reshape(P, 4)
+    c4[:, 0], c4[:, 1], c4[:, 3] = con[:, 0], con[:, 1], con[:, 2]
+    return g
+
+
 def gaussian_backward(s, dL_dmeans2D, dL_dconic, dL_dcolors):
     """Only BACKWARD::preprocess (backward.cu:144-277, 349-399) on caller-supplied blend sums
     (dL_dmeans2D (P,3), dL_dconic (P,2,2), dL_dcolors (P,3), float32): lets a test feed the HIP

@@ -13,7 +13,8 @@ cov[~torch.from_numpy(vis)] = torch.eye(3)[[0, 0, 0, 1, 1, 2], [0, 1, 2, 1, 2, 2
 o = util.oracle_forward(scene, cam, 0, colors_precomp=colors, cov3D_precomp=cov, use_sh=False, use_scale_rot=False)
 dpix = util.fragile_free_dpix(o, cam)
 h = util.hip_forward_backward(scene, cam, 0, dpix, colors_precomp=colors, cov3D_precomp=cov, use_sh=False, use_scale_rot=False)
-og = util.oracle.backward(o, dpix.numpy()); g1 = util.oracle.backward(o, dpix.numpy(), accum_mode=1)
+og = util.oracle.backward(o, dpix.numpy()); g1 = util.oracle.backward(o, dpix.numpy(), accum_mode=1); ex = util.oracle.blend_backward_exact(o, dpix.numpy())
+print("FLAGS", os.environ.get("GSR_DEBUG_FLAGS"), "G1249 exact", ex["dL_dconic"].reshape(-1,4)[1249], "gpu", h["raw_grads"]["dL_dconic"].reshape(-1,4)[1249], "oracle", og["dL_dconic"].reshape(-1,4)[1249])
 a = h["raw_grads"]["dL_dconic"].reshape(-1, 4).astype(np.float64); b = og["dL_dconic"].reshape(-1, 4).astype(np.float64); c = g1["dL_dconic"].reshape(-1,4).astype(np.float64)
 err = np.abs(a - b); i = np.unravel_index(err.argmax(), err.shape)
 print("max|g|", np.abs(b).max(), "argmax err", i, "gpu", a[i], "oracle64", b[i], "oracle32", c[i], "abs err", err[i])
@@ -27,3 +28,11 @@ ok = o["fragile"] == 0
 d = np.abs(h["color"].reshape(3,-1) - o["color"].reshape(3,-1)).max(0)
 print("image maxdiff nonfragile", d[ok].max(), "fragile", d[~ok].max() if (~ok).any() else None, "n fragile", (~ok).sum())
 print("n_contrib mismatches (all pixels)", (h["n_contrib"] != o["n_contrib"]).sum())
+
+ok = o["fragile"] == 0
+rel = np.abs(h["final_T"] - o["final_T"]) / np.maximum(o["final_T"], 1e-30)
+print("final_T rel err max (non fragile)", rel[ok].max(), "mean", rel[ok].mean())
+for k in ("dL_dmeans2D","dL_dconic","dL_dopacity","dL_dcolors"):
+    P = 2500
+    a = h["raw_grads"][k].reshape(P,-1).astype(np.float64); b = ex[k].reshape(P,-1); c = og[k].reshape(P,-1).astype(np.float64)
+    print(k, "gpu-vs-exact", np.abs(a-b).max()/np.abs(b).max(), "oracle-vs-exact", np.abs(c-b).max()/np.abs(b).max())
