@@ -15,8 +15,9 @@
 #include "render_common.h"
 
 #define GSR_BWD_NV 9
+typedef float v2f __attribute__((ext_vector_type(2)));
 
-__global__ void __launch_bounds__(64 * GSR_WAVES_PER_WG, 4) gsr_render_backward_wave_kernel(
+__global__ void __launch_bounds__(64 * GSR_WAVES_PER_WG, 1) gsr_render_backward_wave_kernel(
 	int W, int H, int gx, int ntiles, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
 	const GsrSplat* __restrict__ splat, const float* __restrict__ bg, const float* __restrict__ final_Ts,
 	const uint32_t* __restrict__ n_contrib, const uint32_t* __restrict__ tile_max_contrib,
@@ -41,25 +42,32 @@ __global__ void __launch_bounds__(64 * GSR_WAVES_PER_WG, 4) gsr_render_backward_
 	const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
 	const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;
 
-	// per-pixel state, kept small (36 registers for 4 pixels) so that 4 waves fit per SIMD
-	float T[GSR_PIX_PER_LANE], tfb[GSR_PIX_PER_LANE];  // running T; -T_final * (bg . dL/dpix)
-	float ac0[GSR_PIX_PER_LANE], ac1[GSR_PIX_PER_LANE], ac2[GSR_PIX_PER_LANE];  // accum_rec as the NEXT hit will see it
-	float dp0[GSR_PIX_PER_LANE], dp1[GSR_PIX_PER_LANE], dp2[GSR_PIX_PER_LANE];
+	// Per-pixel state as two float2 "pixel pairs" per lane: pair p holds pixel slots k = 2p, 2p+1
+	// (rows py0 + 8p and py0 + 8p + 4).  All add/mul/fma on pairs compile to v_pk_*_f32 -- two pixels
+	// per VALU issue slot, which is what bounds this kernel (PMC: VALU active ~100 % of the time).
+	// 36 registers of state for 4 pixels, so that 4 waves fit per SIMD.
+	v2f T[2], tfb[2];                 // running T; -T_final * (bg . dL/dpix)
+	v2f ac0[2], ac1[2], ac2[2];       // accum_rec as the NEXT hit will see it
+	v2f dp0[2], dp1[2], dp2[2];
 	int last_contributor[GSR_PIX_PER_LANE];
-	const float pfy0 = (float)py0;
+	v2f pfy[2];
 #pragma unroll
 	for (int k = 0; k < GSR_PIX_PER_LANE; k++) {
 		const int py = py0 + 4 * k;
 		const bool inside = px < W && py < H;
 		const uint32_t pix_id = inside ? (uint32_t)(W * py + px) : 0u;
-		T[k] = inside ? final_Ts[pix_id] : 0.f;
+		const float Tf = inside ? final_Ts[pix_id] : 0.f;
+		const float d0 = inside ? dL_dpixels[pix_id] : 0.f;
+		const float d1 = inside ? dL_dpixels[plane + pix_id] : 0.f;
+		const float d2 = inside ? dL_dpixels[2 * plane + pix_id] : 0.f;
 		last_contributor[k] = inside ? (int)n_contrib[pix_id] : 0;
-		dp0[k] = inside ? dL_dpixels[pix_id] : 0.f;
-		dp1[k] = inside ? dL_dpixels[plane + pix_id] : 0.f;
-		dp2[k] = inside ? dL_dpixels[2 * plane + pix_id] : 0.f;
-		tfb[k] = -T[k] * (bg0 * dp0[k] + bg1 * dp1[k] + bg2 * dp2[k]);
-		ac0[k] = ac1[k] = ac2[k] = 0.f;
+		T[k >> 1][k & 1] = Tf;
+		dp0[k >> 1][k & 1] = d0; dp1[k >> 1][k & 1] = d1; dp2[k >> 1][k & 1] = d2;
+		tfb[k >> 1][k & 1] = -Tf * (bg0 * d0 + bg1 * d1 + bg2 * d2);
+		pfy[k >> 1][k & 1] = (float)py;
 	}
+#pragma unroll
+	for (int p = 0; p < 2; p++) ac0[p] = ac1[p] = ac2[p] = v2f{0.f, 0.f};
 
 	// back to front: batch position q = base + lane maps to range position n - 1 - q
 	float4 ra = make_float4(0, 0, 0, 0), rb = ra, rc = ra;
@@ -97,61 +105,66 @@ __global__ void __launch_bounds__(64 * GSR_WAVES_PER_WG, 4) gsr_render_backward_
 			const int contributor = __float_as_int(Cc.y);  // backward.cu:511-515
 			const uint32_t bands = __builtin_amdgcn_readfirstlane(__float_as_uint(Cc.w));  // wave-uniform
 			const float dx = A.x - pfx;
-			const float ax2 = __fmul_rn(__fmul_rn(A.z, dx), dx), bdx = __fmul_rn(A.w, dx);
-			// per-lane partial sums over its four pixels.  The geometric terms are kept as raw moments
-			// of f = G * dL/dG (sum f dx, f dy, f dx^2, f dx dy, f dy^2); the conic and the 0.5*W / 0.5*H /
-			// -0.5 factors of backward.cu:574-594 are applied once per instance after the reduction.
-			float v[GSR_BWD_NV];
+			const float ax2 = (A.z * dx) * dx, bdx = A.w * dx;  // this file is compiled with -ffp-contract=off
+			// per-lane partial sums over its pixels (one float2 = two pixels, added at the end).  The
+			// geometric terms are kept as raw moments of f = G * dL/dG (sum f dx, f dy, f dx^2, f dx dy,
+			// f dy^2); the conic and the 0.5*W / 0.5*H / -0.5 factors of backward.cu:574-594 are applied
+			// once per instance after the reduction.
+			v2f acc[GSR_BWD_NV];
 #pragma unroll
-			for (int i = 0; i < GSR_BWD_NV; i++) v[i] = 0.f;
+			for (int i = 0; i < GSR_BWD_NV; i++) acc[i] = v2f{0.f, 0.f};
 			bool any = false;
 #pragma unroll
-			for (int k = 0; k < GSR_PIX_PER_LANE; k++) {
-				if (!(bands & (1u << k))) continue;  // this 16x4 band cannot be reached: scalar branch
-				const float dy = A.y - (pfy0 + 4.0f * k);  // pixel row as an exact small integer
-				const float power = gsr_pair_power(ax2, bdx, B.x, dy);
-				const float G = __expf(power);
-				const float alpha = fminf(0.99f, B.y * G);
-				const bool hit = contributor < last_contributor[k] && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
-				if (__ballot(hit) == 0ull) continue;  // wave-uniform
-				if (hit) {
-					any = true;
-					const float inv1ma = __builtin_amdgcn_rcpf(1.f - alpha);  // 1 ulp; exact IEEE division changed no parity figure
-					T[k] = T[k] * inv1ma;
-					const float dchannel_dcolor = alpha * T[k];
-					// accum_rec and (c - accum_rec) cancel heavily when neighbouring colours are close, so the
-					// recurrence and this dot product keep the reference's exact operation order with no FMA
-					// contraction (backward.cu:553-559); everything else may contract
-					float dL_dalpha = __fadd_rn(__fadd_rn(__fmul_rn(__fsub_rn(B.z, ac0[k]), dp0[k]),
-					                                      __fmul_rn(__fsub_rn(B.w, ac1[k]), dp1[k])),
-					                            __fmul_rn(__fsub_rn(Cc.x, ac2[k]), dp2[k]));
-					// the reference updates accum_rec lazily at the NEXT hit from (last_alpha, last_color);
-					// doing it now uses the same operands and yields the same bits, without keeping them
-					const float oma = __fsub_rn(1.f, alpha);
-					ac0[k] = __fadd_rn(__fmul_rn(alpha, B.z), __fmul_rn(oma, ac0[k]));
-					ac1[k] = __fadd_rn(__fmul_rn(alpha, B.w), __fmul_rn(oma, ac1[k]));
-					ac2[k] = __fadd_rn(__fmul_rn(alpha, Cc.x), __fmul_rn(oma, ac2[k]));
-					// (this file is compiled with -ffp-contract=off; the accumulations below ask for FMA
-					// explicitly: one rounding instead of two, and no effect on the operation order)
-					v[6] = __builtin_fmaf(dchannel_dcolor, dp0[k], v[6]);
-					v[7] = __builtin_fmaf(dchannel_dcolor, dp1[k], v[7]);
-					v[8] = __builtin_fmaf(dchannel_dcolor, dp2[k], v[8]);
-					dL_dalpha *= T[k];
-					dL_dalpha += tfb[k] * inv1ma;
-					v[5] = __builtin_fmaf(G, dL_dalpha, v[5]);  // dL/dopacity
-					const float f = (B.y * dL_dalpha) * G;      // dL/dG * G
-					const float fdx = f * dx, fdy = f * dy;
-					v[0] += fdx;
-					v[1] += fdy;
-					v[2] = __builtin_fmaf(fdx, dx, v[2]);
-					v[3] = __builtin_fmaf(fdx, dy, v[3]);
-					v[4] = __builtin_fmaf(fdy, dy, v[4]);
-				}
+			for (int p = 0; p < 2; p++) {
+				if (!(bands & (3u << (2 * p)))) continue;  // neither 16x4 band of this pair can be reached
+				// power = -0.5f * (a*dx*dx + c*dy*dy) - b*dx*dy in the reference's operation order
+				const v2f dy = A.y - pfy[p];
+				const v2f power = -0.5f * (ax2 + (B.x * dy) * dy) - bdx * dy;
+				const v2f G = {__expf(power.x), __expf(power.y)};
+				const v2f og = B.y * G;
+				const v2f alpha = {fminf(0.99f, og.x), fminf(0.99f, og.y)};
+				const bool hit0 = contributor < last_contributor[2 * p] && !(power.x > 0.0f) && !(alpha.x < 1.0f / 255.0f);
+				const bool hit1 = contributor < last_contributor[2 * p + 1] && !(power.y > 0.0f) && !(alpha.y < 1.0f / 255.0f);
+				if (__ballot(hit0 || hit1) == 0ull) continue;  // wave-uniform
+				any = true;  // (lanes without a hit add exact zeros below)
+				const v2f oma = 1.f - alpha;
+				const v2f inv1ma = {__builtin_amdgcn_rcpf(oma.x), __builtin_amdgcn_rcpf(oma.y)};  // 1 ulp; IEEE division changed no parity figure
+				const v2f Tn = T[p] * inv1ma;
+				// accum_rec and (c - accum_rec) cancel heavily when neighbouring colours are close: reference
+				// operation order, no contraction (backward.cu:553-559)
+				v2f dL_dalpha = ((B.z - ac0[p]) * dp0[p] + (B.w - ac1[p]) * dp1[p]) + (Cc.x - ac2[p]) * dp2[p];
+				// the reference updates accum_rec lazily at the NEXT hit from (last_alpha, last_color);
+				// doing it now uses the same operands and yields the same bits, without keeping them
+				const v2f n0 = alpha * B.z + oma * ac0[p];
+				const v2f n1 = alpha * B.w + oma * ac1[p];
+				const v2f n2 = alpha * Cc.x + oma * ac2[p];
+				dL_dalpha = dL_dalpha * Tn + tfb[p] * inv1ma;
+				// zero the partials of the pixel that did not hit, and leave its state untouched
+				const v2f hm = {hit0 ? 1.f : 0.f, hit1 ? 1.f : 0.f};
+				const v2f dch = (alpha * Tn) * hm;      // dchannel_dcolor
+				const v2f dla = dL_dalpha * hm;
+				T[p] = v2f{hit0 ? Tn.x : T[p].x, hit1 ? Tn.y : T[p].y};
+				ac0[p] = v2f{hit0 ? n0.x : ac0[p].x, hit1 ? n0.y : ac0[p].y};
+				ac1[p] = v2f{hit0 ? n1.x : ac1[p].x, hit1 ? n1.y : ac1[p].y};
+				ac2[p] = v2f{hit0 ? n2.x : ac2[p].x, hit1 ? n2.y : ac2[p].y};
+				acc[6] = __builtin_elementwise_fma(dch, dp0[p], acc[6]);
+				acc[7] = __builtin_elementwise_fma(dch, dp1[p], acc[7]);
+				acc[8] = __builtin_elementwise_fma(dch, dp2[p], acc[8]);
+				acc[5] = __builtin_elementwise_fma(G, dla, acc[5]);  // dL/dopacity
+				const v2f f = (B.y * dla) * G;                        // dL/dG * G
+				const v2f fdx = f * dx, fdy = f * dy;
+				acc[0] += fdx;
+				acc[1] += fdy;
+				acc[2] = __builtin_elementwise_fma(fdx, v2f{dx, dx}, acc[2]);
+				acc[3] = __builtin_elementwise_fma(fdx, dy, acc[3]);
+				acc[4] = __builtin_elementwise_fma(fdy, dy, acc[4]);
 			}
 			if (__ballot(any)) {  // wave-uniform
+				float v[GSR_BWD_NV];
+#pragma unroll
+				for (int i = 0; i < GSR_BWD_NV; i++) v[i] = acc[i].x + acc[i].y;
 				const float t8 = gsr_bfly8(v, lane);           // group g holds the total of v[gsr_bfly_index(g)]
 				const float t9 = gsr_wave_sum_to_lane63(v[8]);  // lane 63 holds the total of v[8]
-				// totals of the five moments to the lanes that finish the formulas (group leaders)
 				// v[0] ends in group 0 (lane 0), v[1] in group 4 (lane 32): scalar broadcasts
 				const float sx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, t8), 0));
 				const float sy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, t8), 32));

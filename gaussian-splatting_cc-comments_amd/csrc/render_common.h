@@ -8,7 +8,7 @@
 #pragma once
 #include "gsr_internal.h"
 
-#define GSR_WAVES_PER_WG 4
+#define GSR_WAVES_PER_WG 1
 #define GSR_PIX_PER_LANE 4
 
 // Conservative, exact-result-preserving culling.  alpha = o*exp(-q/2) with
