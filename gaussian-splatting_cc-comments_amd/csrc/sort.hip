@@ -81,9 +81,10 @@ __global__ void __launch_bounds__(GSR_SORT_THREADS) gsr_radix_scatter_kernel(
 	uint32_t* __restrict__ vals_out, size_t n, int shift, int nbits, const uint32_t* __restrict__ table, int nblocks,
 	const uint32_t* __restrict__ digit_total)
 {
-	__shared__ uint32_t wcount[GSR_SORT_THREADS / 64][GSR_SORT_RADIX];  // per-wave digit counts, then bases
-	__shared__ uint32_t dbase[GSR_SORT_RADIX];
+	__shared__ uint32_t wcount[GSR_SORT_THREADS / 64][GSR_SORT_RADIX];  // per-wave digit counts, then local bases
+	__shared__ uint32_t gofs[GSR_SORT_RADIX];                           // global base of a digit minus its local base
 	__shared__ uint32_t wsum[GSR_SORT_THREADS / 64];
+	__shared__ uint32_t skey[GSR_SORT_TILE], sval[GSR_SORT_TILE];       // the block's elements in digit order
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	const uint32_t mask = (1u << nbits) - 1u;
 
@@ -91,6 +92,7 @@ __global__ void __launch_bounds__(GSR_SORT_THREADS) gsr_radix_scatter_kernel(
 	for (int w = 0; w < GSR_SORT_THREADS / 64; w++) wcount[w][threadIdx.x] = 0;
 
 	// global exclusive base of digit d = (sum of totals of smaller digits) + this block's offset in d
+	uint32_t my_gbase;
 	{
 		const uint32_t v = digit_total[threadIdx.x];
 		uint32_t incl = v;
@@ -105,7 +107,7 @@ __global__ void __launch_bounds__(GSR_SORT_THREADS) gsr_radix_scatter_kernel(
 #pragma unroll
 		for (int w = 0; w < GSR_SORT_THREADS / 64; w++)
 			if (w < wave) wb += wsum[w];
-		dbase[threadIdx.x] = wb + incl - v + table[(size_t)threadIdx.x * nblocks + blockIdx.x];
+		my_gbase = wb + incl - v + table[(size_t)threadIdx.x * nblocks + blockIdx.x];
 	}
 	__syncthreads();
 
@@ -135,26 +137,50 @@ __global__ void __launch_bounds__(GSR_SORT_THREADS) gsr_radix_scatter_kernel(
 		rank[it] = old + (uint32_t)__popcll(peers & ((1ull << lane) - 1ull));
 	}
 	__syncthreads();
-	// per digit: turn per-wave counts into per-wave exclusive bases (+ global base)
+	// per digit (thread d): block total -> exclusive scan over digits = local base of the digit inside
+	// the block; per-wave counts -> per-wave local bases
 	{
-		uint32_t run = dbase[threadIdx.x];
+		uint32_t c[GSR_SORT_THREADS / 64], tot = 0;
 #pragma unroll
-		for (int w = 0; w < GSR_SORT_THREADS / 64; w++) {
-			const uint32_t c = wcount[w][threadIdx.x];
-			wcount[w][threadIdx.x] = run;
-			run += c;
+		for (int w = 0; w < GSR_SORT_THREADS / 64; w++) { c[w] = wcount[w][threadIdx.x]; tot += c[w]; }
+		uint32_t incl = tot;
+#pragma unroll
+		for (int off = 1; off < 64; off <<= 1) {
+			const uint32_t t = __shfl_up(incl, off, 64);
+			if (lane >= off) incl += t;
 		}
+		if (lane == 63) wsum[wave] = incl;
+		__syncthreads();
+		uint32_t wb = 0;
+#pragma unroll
+		for (int w = 0; w < GSR_SORT_THREADS / 64; w++)
+			if (w < wave) wb += wsum[w];
+		uint32_t run = wb + incl - tot;  // local exclusive base of digit threadIdx.x
+		gofs[threadIdx.x] = my_gbase - run;
+#pragma unroll
+		for (int w = 0; w < GSR_SORT_THREADS / 64; w++) { wcount[w][threadIdx.x] = run; run += c[w]; }
 	}
 	__syncthreads();
+	// stage the elements in digit order, then write them out linearly: consecutive threads store to
+	// consecutive addresses inside each digit's run (a direct scatter makes every lane of a store
+	// instruction hit a different cache line)
 #pragma unroll
 	for (int it = 0; it < GSR_SORT_ITEMS; it++) {
 		const size_t i = gsr_sort_index(blockIdx.x, wave, it, lane);
 		if (i < n) {
-			const uint32_t d = (key[it] >> shift) & mask;
-			const uint32_t dst = mycount[d] + rank[it];
-			keys_out[dst] = key[it];
-			vals_out[dst] = val[it];
+			const uint32_t lp = mycount[(key[it] >> shift) & mask] + rank[it];
+			skey[lp] = key[it];
+			sval[lp] = val[it];
 		}
+	}
+	__syncthreads();
+	const size_t first = (size_t)blockIdx.x * GSR_SORT_TILE;
+	const uint32_t count = (uint32_t)((n - first < (size_t)GSR_SORT_TILE) ? (n - first) : (size_t)GSR_SORT_TILE);
+	for (uint32_t i = threadIdx.x; i < count; i += GSR_SORT_THREADS) {
+		const uint32_t k = skey[i];
+		const uint32_t dst = gofs[(k >> shift) & mask] + i;
+		keys_out[dst] = k;
+		vals_out[dst] = sval[i];
 	}
 }
 
