@@ -33,9 +33,28 @@ __device__ __forceinline__ float gsr_sh_channel(int deg, const float* sh, int ch
 	return result + 0.5f;
 }
 
-__global__ void __launch_bounds__(GSR_PREPROCESS_BLOCK) gsr_preprocess_kernel(GsrPreprocessArgs a)
+#define GSR_SH_ROW4 13  // LDS row stride in float4: 12 used + 1 pad -> conflict-free 16-byte accesses per row
+
+__global__ void __launch_bounds__(GSR_PREPROCESS_BLOCK) gsr_preprocess_kernel(GsrPreprocessArgs a, int sh_via_lds)
 {
+	__shared__ float4 s_sh[GSR_PREPROCESS_BLOCK / 64][64 * GSR_SH_ROW4];
 	const int idx = blockIdx.x * GSR_PREPROCESS_BLOCK + threadIdx.x;
+	// The wave's 64 x 48 SH floats are contiguous in HBM: stage them into LDS with coalesced float4
+	// loads (a lane reading its own 192-byte row makes every load instruction touch 64 lines)
+	if (sh_via_lds) {
+		const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+		const int wave_first = blockIdx.x * GSR_PREPROCESS_BLOCK + wave * 64;
+		const int nrows = min(64, a.P - wave_first);
+		if (nrows > 0) {
+			const float4* src = reinterpret_cast<const float4*>(a.shs + (size_t)wave_first * 48);
+#pragma unroll
+			for (int it = 0; it < 12; it++) {
+				const int f = it * 64 + lane;
+				if (f < nrows * 12) s_sh[wave][(f / 12) * GSR_SH_ROW4 + (f % 12)] = src[f];
+			}
+		}
+		__builtin_amdgcn_wave_barrier();
+	}
 	uint32_t tiles = 0;
 	int radius_out = 0;
 	uint32_t depth_key = 0xFFFFFFFFu;  // culled Gaussians sort behind every visible one
@@ -90,7 +109,8 @@ __global__ void __launch_bounds__(GSR_PREPROCESS_BLOCK) gsr_preprocess_kernel(Gs
 				float dx = p_orig.x - a.cam_pos[0], dy = p_orig.y - a.cam_pos[1], dz = p_orig.z - a.cam_pos[2];
 				float len = sqrtf(dx * dx + dy * dy + dz * dz);
 				dx = dx / len; dy = dy / len; dz = dz / len;
-				const float* sh = a.shs + (size_t)idx * a.M * 3;
+				const float* sh = sh_via_lds ? reinterpret_cast<const float*>(&s_sh[threadIdx.x >> 6][(threadIdx.x & 63) * GSR_SH_ROW4])
+				                             : a.shs + (size_t)idx * a.M * 3;
 #pragma unroll
 				for (int ch = 0; ch < 3; ch++) {
 					float v = gsr_sh_channel(a.D, sh, ch, dx, dy, dz);
@@ -133,7 +153,9 @@ __global__ void __launch_bounds__(GSR_PREPROCESS_BLOCK) gsr_preprocess_kernel(Gs
 void gsr_launch_preprocess(const GsrPreprocessArgs& a, hipStream_t s)
 {
 	const int nb = (a.P + GSR_PREPROCESS_BLOCK - 1) / GSR_PREPROCESS_BLOCK;
-	hipLaunchKernelGGL(gsr_preprocess_kernel, dim3(nb), dim3(GSR_PREPROCESS_BLOCK), 0, s, a);
+	// LDS-transposed SH path: the flagship layout (16 coefficients), 16-byte aligned tensor
+	const int sh_via_lds = (a.shs && !a.colors_precomp && a.M == 16 && ((uintptr_t)a.shs & 15u) == 0) ? 1 : 0;
+	hipLaunchKernelGGL(gsr_preprocess_kernel, dim3(nb), dim3(GSR_PREPROCESS_BLOCK), 0, s, a, sh_via_lds);
 }
 
 // rasterizer_impl.cu:56-69 checkFrustum: only the view-space z test of in_frustum survives
