@@ -15,17 +15,23 @@
 #include "gsr_internal.h"
 
 #define GSR_SORT_THREADS 256
-#define GSR_SORT_ITEMS 16
-#define GSR_SORT_TILE (GSR_SORT_THREADS * GSR_SORT_ITEMS)  // elements per workgroup: 4096
 #define GSR_SORT_RADIX 256
+// Elements per thread: 16 (4096 per workgroup: long, well-coalesced digit runs) for instance-sized
+// sorts; 4 for the Gaussian-sized depth sort, which would otherwise run on fewer workgroups than
+// there are CUs with 16 serial ranking rounds each (measured 18 us per pass at P = 1M).
+#define GSR_SORT_ITEMS_LARGE 16
+#define GSR_SORT_ITEMS_SMALL 4
+#define GSR_SORT_SMALL_N (4u << 20)
 
 // element index of item `it` of this lane: each wave owns a contiguous run of 64 * ITEMS elements,
 // visited 64 at a time, so element order == (wave, it, lane) order and loads are coalesced
+template <int ITEMS>
 __device__ __forceinline__ size_t gsr_sort_index(int block, int wave, int it, int lane)
 {
-	return (size_t)block * GSR_SORT_TILE + (size_t)wave * (64 * GSR_SORT_ITEMS) + (size_t)it * 64 + lane;
+	return (size_t)block * (GSR_SORT_THREADS * ITEMS) + (size_t)wave * (64 * ITEMS) + (size_t)it * 64 + lane;
 }
 
+template <int ITEMS>
 __global__ void __launch_bounds__(GSR_SORT_THREADS) gsr_radix_hist_kernel(const uint32_t* __restrict__ keys, size_t n,
                                                                           int shift, uint32_t mask,
                                                                           uint32_t* __restrict__ table, int nblocks)
@@ -35,8 +41,8 @@ __global__ void __launch_bounds__(GSR_SORT_THREADS) gsr_radix_hist_kernel(const 
 	__syncthreads();
 	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll
-	for (int it = 0; it < GSR_SORT_ITEMS; it++) {
-		const size_t i = gsr_sort_index(blockIdx.x, wave, it, lane);
+	for (int it = 0; it < ITEMS; it++) {
+		const size_t i = gsr_sort_index<ITEMS>(blockIdx.x, wave, it, lane);
 		if (i < n) atomicAdd(&hist[(keys[i] >> shift) & mask], 1u);
 	}
 	__syncthreads();
@@ -76,6 +82,7 @@ __global__ void __launch_bounds__(GSR_SORT_THREADS) gsr_radix_rowscan_kernel(uin
 	if (threadIdx.x == 0) digit_total[blockIdx.x] = carry;
 }
 
+template <int ITEMS>
 __global__ void __launch_bounds__(GSR_SORT_THREADS) gsr_radix_scatter_kernel(
 	const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, uint32_t* __restrict__ keys_out,
 	uint32_t* __restrict__ vals_out, size_t n, int shift, int nbits, const uint32_t* __restrict__ table, int nblocks,
@@ -84,7 +91,8 @@ __global__ void __launch_bounds__(GSR_SORT_THREADS) gsr_radix_scatter_kernel(
 	__shared__ uint32_t wcount[GSR_SORT_THREADS / 64][GSR_SORT_RADIX];  // per-wave digit counts, then local bases
 	__shared__ uint32_t gofs[GSR_SORT_RADIX];                           // global base of a digit minus its local base
 	__shared__ uint32_t wsum[GSR_SORT_THREADS / 64];
-	__shared__ uint32_t skey[GSR_SORT_TILE], sval[GSR_SORT_TILE];       // the block's elements in digit order
+	constexpr int TILE = GSR_SORT_THREADS * ITEMS;
+	__shared__ uint32_t skey[TILE], sval[TILE];       // the block's elements in digit order
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	const uint32_t mask = (1u << nbits) - 1u;
 
@@ -111,11 +119,11 @@ __global__ void __launch_bounds__(GSR_SORT_THREADS) gsr_radix_scatter_kernel(
 	}
 	__syncthreads();
 
-	uint32_t key[GSR_SORT_ITEMS], val[GSR_SORT_ITEMS], rank[GSR_SORT_ITEMS];
+	uint32_t key[ITEMS], val[ITEMS], rank[ITEMS];
 	uint32_t* mycount = wcount[wave];
 #pragma unroll
-	for (int it = 0; it < GSR_SORT_ITEMS; it++) {
-		const size_t i = gsr_sort_index(blockIdx.x, wave, it, lane);
+	for (int it = 0; it < ITEMS; it++) {
+		const size_t i = gsr_sort_index<ITEMS>(blockIdx.x, wave, it, lane);
 		const bool valid = i < n;
 		key[it] = valid ? keys_in[i] : 0u;
 		val[it] = valid ? vals_in[i] : 0u;
@@ -165,8 +173,8 @@ __global__ void __launch_bounds__(GSR_SORT_THREADS) gsr_radix_scatter_kernel(
 	// consecutive addresses inside each digit's run (a direct scatter makes every lane of a store
 	// instruction hit a different cache line)
 #pragma unroll
-	for (int it = 0; it < GSR_SORT_ITEMS; it++) {
-		const size_t i = gsr_sort_index(blockIdx.x, wave, it, lane);
+	for (int it = 0; it < ITEMS; it++) {
+		const size_t i = gsr_sort_index<ITEMS>(blockIdx.x, wave, it, lane);
 		if (i < n) {
 			const uint32_t lp = mycount[(key[it] >> shift) & mask] + rank[it];
 			skey[lp] = key[it];
@@ -174,8 +182,8 @@ __global__ void __launch_bounds__(GSR_SORT_THREADS) gsr_radix_scatter_kernel(
 		}
 	}
 	__syncthreads();
-	const size_t first = (size_t)blockIdx.x * GSR_SORT_TILE;
-	const uint32_t count = (uint32_t)((n - first < (size_t)GSR_SORT_TILE) ? (n - first) : (size_t)GSR_SORT_TILE);
+	const size_t first = (size_t)blockIdx.x * TILE;
+	const uint32_t count = (uint32_t)((n - first < (size_t)TILE) ? (n - first) : (size_t)TILE);
 	for (uint32_t i = threadIdx.x; i < count; i += GSR_SORT_THREADS) {
 		const uint32_t k = skey[i];
 		const uint32_t dst = gofs[(k >> shift) & mask] + i;
@@ -186,10 +194,25 @@ __global__ void __launch_bounds__(GSR_SORT_THREADS) gsr_radix_scatter_kernel(
 
 int gsr_radix_num_passes(int nbits_total) { return (nbits_total + 7) / 8; }
 
+static inline int gsr_sort_items(size_t n) { return n <= GSR_SORT_SMALL_N ? GSR_SORT_ITEMS_SMALL : GSR_SORT_ITEMS_LARGE; }
+
 size_t gsr_radix_table_bytes(size_t n)
 {
-	const size_t nblocks = (n + GSR_SORT_TILE - 1) / GSR_SORT_TILE;
+	const size_t tile = (size_t)GSR_SORT_THREADS * gsr_sort_items(n);
+	const size_t nblocks = (n + tile - 1) / tile;
 	return gsr_align_up((nblocks * GSR_SORT_RADIX + GSR_SORT_RADIX) * sizeof(uint32_t));
+}
+
+template <int ITEMS>
+static void gsr_radix_pass(const uint32_t* ki, const uint32_t* vi, uint32_t* ko, uint32_t* vo, size_t n, int shift, int bits,
+                           uint32_t* table, uint32_t* digit_total, hipStream_t s)
+{
+	const int nblocks = (int)((n + (size_t)GSR_SORT_THREADS * ITEMS - 1) / ((size_t)GSR_SORT_THREADS * ITEMS));
+	const uint32_t mask = (1u << bits) - 1u;
+	hipLaunchKernelGGL(gsr_radix_hist_kernel<ITEMS>, dim3(nblocks), dim3(GSR_SORT_THREADS), 0, s, ki, n, shift, mask, table, nblocks);
+	hipLaunchKernelGGL(gsr_radix_rowscan_kernel, dim3(GSR_SORT_RADIX), dim3(GSR_SORT_THREADS), 0, s, table, nblocks, digit_total);
+	hipLaunchKernelGGL(gsr_radix_scatter_kernel<ITEMS>, dim3(nblocks), dim3(GSR_SORT_THREADS), 0, s, ki, vi, ko, vo, n, shift, bits,
+	                   table, nblocks, digit_total);
 }
 
 // Sorts on key bits [0, nbits_total).  Ping-pongs between (k0,v0) and (k1,v1); the sorted result
@@ -200,19 +223,18 @@ void gsr_radix_sort_u32(uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v1, 
 	const int npass = gsr_radix_num_passes(nbits_total);
 	*result_in_first = (npass % 2 == 0) ? 1 : 0;
 	if (n == 0 || npass == 0) { *result_in_first = 1; return; }
-	const int nblocks = (int)((n + GSR_SORT_TILE - 1) / GSR_SORT_TILE);
+	const int items = gsr_sort_items(n);
+	const size_t tile = (size_t)GSR_SORT_THREADS * items;
+	const size_t nblocks = (n + tile - 1) / tile;
 	uint32_t* table = (uint32_t*)table_mem;
-	uint32_t* digit_total = table + (size_t)nblocks * GSR_SORT_RADIX;
+	uint32_t* digit_total = table + nblocks * GSR_SORT_RADIX;
 	int shift = 0;
 	for (int p = 0; p < npass; p++) {
 		const int bits = (nbits_total - shift + (npass - p) - 1) / (npass - p);  // spread bits evenly over passes
-		const uint32_t mask = (1u << bits) - 1u;
 		uint32_t *ki = (p % 2 == 0) ? k0 : k1, *vi = (p % 2 == 0) ? v0 : v1;
 		uint32_t *ko = (p % 2 == 0) ? k1 : k0, *vo = (p % 2 == 0) ? v1 : v0;
-		hipLaunchKernelGGL(gsr_radix_hist_kernel, dim3(nblocks), dim3(GSR_SORT_THREADS), 0, s, ki, n, shift, mask, table, nblocks);
-		hipLaunchKernelGGL(gsr_radix_rowscan_kernel, dim3(GSR_SORT_RADIX), dim3(GSR_SORT_THREADS), 0, s, table, nblocks, digit_total);
-		hipLaunchKernelGGL(gsr_radix_scatter_kernel, dim3(nblocks), dim3(GSR_SORT_THREADS), 0, s, ki, vi, ko, vo, n, shift, bits,
-		                   table, nblocks, digit_total);
+		if (items == GSR_SORT_ITEMS_SMALL) gsr_radix_pass<GSR_SORT_ITEMS_SMALL>(ki, vi, ko, vo, n, shift, bits, table, digit_total, s);
+		else gsr_radix_pass<GSR_SORT_ITEMS_LARGE>(ki, vi, ko, vo, n, shift, bits, table, digit_total, s);
 		shift += bits;
 	}
 }
