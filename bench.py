@@ -26,6 +26,22 @@ import torch.distributed as dist  # noqa: E402
 import gsr_scene  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, corrected as
+# MI355X_MICROARCH.md "HBM" prescribes) of this same command, summarised by tools/pmc_summary.py
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r1_pmc_summary.json")
+KERNEL_SYMBOL = {"render_backward": "gsr_render_backward_wave_kernel", "render_forward": "gsr_render_forward_wave_kernel",
+                 "gaussian_backward": "gsr_gaussian_backward_kernel", "preprocess": "gsr_preprocess_kernel",
+                 "duplicate_keys": "gsr_duplicate_keys_kernel", "tile_ranges": "gsr_tile_ranges_kernel"}
+
+
+def pmc_traffic(stage, workload):
+    try:
+        d = json.load(open(PMC_SUMMARY))
+        if d.get("_workload") != workload:
+            return None
+        return d[KERNEL_SYMBOL[stage]].get("hbm_traffic_bytes")
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def algorithmic_bytes(P, V, R, Rp, N, T, M):
@@ -89,9 +105,16 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # GSR_BENCH_BACKEND=gloo (debug only): lets several ranks share ONE GPU to rehearse the N > 1 code path
+    backend = os.environ.get("GSR_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % max(1, torch.cuda.device_count())
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
@@ -190,7 +213,9 @@ def main():
         if dom:
             a = kern[dom]["GBps"] or 0.0
             roofline = dict(kernel=dom, bound="hbm", achieved=a, peak=HBM_PEAK_GBS, unit="GB/s",
-                            frac=round(a / HBM_PEAK_GBS, 4), traffic=None,
+                            frac=round(a / HBM_PEAK_GBS, 4), traffic=pmc_traffic(dom, args.config),
+                            note="this kernel is VALU-issue-bound (PMC: SQ_ACTIVE_INST_VALU ~ 100 % of its duration), "
+                                 "so its HBM fraction is small by construction; see 'kernels' for the streaming stages",
                             avg_launch_ms=kern[dom]["ms"], algorithmic_bytes_per_launch=kern[dom]["algorithmic_bytes"],
                             step_algorithmic_bytes=step_bytes,
                             step_GBps=round(step_bytes / (ms_per_step * 1e-3) / 1e9, 1),

@@ -3,7 +3,7 @@ per kernel, the average of every counter per dispatch and the derived HBM traffi
 Traffic follows MI355X_MICROARCH.md "HBM": FETCH_SIZE and WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE
 reports half of the bytes of a wide (16 B/lane) read stream, so reads = 2 * FETCH_SIZE * 1024;
 WRITE_SIZE is exact for 16-B-per-lane stores.  Narrower accesses are uncalibrated (noted per kernel).
-usage: python tools/pmc_summary.py gpurun_out profiles/r1_pmc_summary.json"""
+usage: python tools/pmc_summary.py gpurun_out profiles/r1_pmc_summary.json [workload]"""
 import collections
 import csv
 import glob
@@ -14,11 +14,13 @@ src, dst = sys.argv[1], sys.argv[2]
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(f"{src}/pmc_*/*/*_counter_collection.csv"):
     for r in csv.DictReader(open(f)):
-        k = r["Kernel_Name"].split("(")[0]
+        k = r["Kernel_Name"].split("(")[0].replace("void ", "")
         if k.startswith("gsr_"):
             agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 out = {}
 for k, c in sorted(agg.items()):
+    if not c:
+        continue
     e = {n: sum(v) / len(v) for n, v in c.items()}
     e["dispatches_sampled"] = max(len(v) for v in c.values())
     if "FETCH_SIZE" in e and "WRITE_SIZE" in e:
@@ -28,5 +30,6 @@ for k, c in sorted(agg.items()):
     if "SQ_ACTIVE_INST_VALU" in e and "SQ_WAVE_CYCLES" in e:
         e["valu_active_over_wave_cycles"] = e["SQ_ACTIVE_INST_VALU"] / e["SQ_WAVE_CYCLES"]
     out[k] = e
+out["_workload"] = sys.argv[3] if len(sys.argv) > 3 else "C3"
 json.dump(out, open(dst, "w"), indent=1, sort_keys=True)
 print("wrote", dst, "kernels:", len(out))
