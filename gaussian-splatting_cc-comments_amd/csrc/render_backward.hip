@@ -68,6 +68,16 @@ __global__ void __launch_bounds__(64 * GSR_WAVES_PER_WG, 1) gsr_render_backward_
 	}
 #pragma unroll
 	for (int p = 0; p < 2; p++) ac0[p] = ac1[p] = ac2[p] = v2f{0.f, 0.f};
+	// wave-uniform: the largest n_contrib among the 128 pixels of each pair; instances at or beyond it
+	// were blended into none of them, so the pair is skipped without evaluating anything
+	int pair_last[2];
+#pragma unroll
+	for (int p = 0; p < 2; p++) {
+		int m = max(last_contributor[2 * p], last_contributor[2 * p + 1]);
+#pragma unroll
+		for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_xor(m, off, 64));
+		pair_last[p] = __builtin_amdgcn_readfirstlane(m);
+	}
 
 	// back to front: batch position q = base + lane maps to range position n - 1 - q
 	float4 ra = make_float4(0, 0, 0, 0), rb = ra, rc = ra;
@@ -102,7 +112,7 @@ __global__ void __launch_bounds__(64 * GSR_WAVES_PER_WG, 1) gsr_render_backward_
 			const float4 A = rec[0][j];   // x, y, conic a, conic b
 			const float4 B = rec[1][j];   // conic c, opacity, r, g
 			const float4 Cc = rec[2][j];  // b, position in the full range, slot, band mask
-			const int contributor = __float_as_int(Cc.y);  // backward.cu:511-515
+			const int contributor = __builtin_amdgcn_readfirstlane(__float_as_int(Cc.y));  // backward.cu:511-515; wave-uniform
 			const uint32_t bands = __builtin_amdgcn_readfirstlane(__float_as_uint(Cc.w));  // wave-uniform
 			const float dx = A.x - pfx;
 			const float ax2 = (A.z * dx) * dx, bdx = A.w * dx;  // this file is compiled with -ffp-contract=off
@@ -116,7 +126,7 @@ __global__ void __launch_bounds__(64 * GSR_WAVES_PER_WG, 1) gsr_render_backward_
 			bool any = false;
 #pragma unroll
 			for (int p = 0; p < 2; p++) {
-				if (!(bands & (3u << (2 * p)))) continue;  // neither 16x4 band of this pair can be reached
+				if (!(bands & (3u << (2 * p))) || contributor >= pair_last[p]) continue;  // scalar branch: no band of this pair can be reached
 				// power = -0.5f * (a*dx*dx + c*dy*dy) - b*dx*dy in the reference's operation order
 				const v2f dy = A.y - pfy[p];
 				const v2f power = -0.5f * (ax2 + (B.x * dy) * dy) - bdx * dy;

@@ -89,6 +89,7 @@ __global__ void __launch_bounds__(64 * GSR_WAVES_PER_WG) gsr_render_forward_wave
 #pragma unroll
 			for (int k = 0; k < GSR_PIX_PER_LANE; k++) {
 				if (!(bands & (1u << k))) continue;  // this 16x4 band cannot be reached: scalar branch
+				if (__ballot(Trun[k] > 0.f) == 0ull) continue;  // all 64 pixels of the band are done
 				const float dy = A.y - pfy[k];
 				const float power = gsr_pair_power(ax2, bdx, B.x, dy);
 				const float alpha = fminf(0.99f, B.y * __expf(power));

@@ -1,0 +1,115 @@
+"""GPU: the render() caller (gaussian_renderer/__init__.py:18-124 contract) and its two Python-side
+alternates, plus edge cases of the drop-in surface: clones with identical depth (sort stability),
+opacities 0 and 1, debug mode and the snapshot dump."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import gsr_scene
+import util
+
+pytestmark = pytest.mark.gpu
+
+
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+
+
+def _cam_to(cam, dev):
+    return cam._replace(world_view_transform=cam.world_view_transform.to(dev), full_proj_transform=cam.full_proj_transform.to(dev),
+                        camera_center=cam.camera_center.to(dev))
+
+
+def test_render_contract_and_python_alternates_agree():
+    _need_gpu()
+    import gsr_model
+    from gaussian_renderer import render
+    dev = torch.device("cuda:0")
+    scene = gsr_scene.make_scene(5000, -3.2, sh_degree=3, seed=12)
+    cam = _cam_to(gsr_scene.ring_camera(240, 136, 2, 8), dev)
+    g = torch.Generator().manual_seed(3)
+    dpix = torch.randn(3, 136, 240, generator=g).to(dev)
+    outs = {}
+    for name, kw in (("kernel", {}), ("sh_python", dict(convert_SHs_python=True)), ("cov_python", dict(compute_cov3D_python=True))):
+        pc = gsr_model.GaussianParams.from_activated(scene.means3D, scene.shs, scene.scales, scene.rotations, scene.opacities,
+                                                     device=dev, active_sh_degree=2)
+        r = render(cam, pc, gsr_model.pipeline_params(**kw), scene.bg.to(dev))
+        assert set(r) == {"render", "viewspace_points", "visibility_filter", "radii"}
+        assert r["render"].shape == (3, 136, 240) and r["radii"].dtype == torch.int32
+        assert torch.equal(r["visibility_filter"], r["radii"] > 0)
+        r["render"].backward(dpix)
+        assert r["viewspace_points"].grad is not None and r["viewspace_points"].grad.shape == (5000, 3)
+        assert float(r["viewspace_points"].grad[:, 2].abs().max()) == 0.0
+        outs[name] = (r["render"].detach(), [p.grad.clone() for p in pc.parameters()], r["radii"], r["viewspace_points"].grad.clone())
+    img0, grads0, radii0, vs0 = outs["kernel"]
+    for name in ("sh_python", "cov_python"):
+        img, grads, radii, vs = outs[name]
+        # different roundings of colour / covariance may move a radius by one pixel or flip a threshold
+        assert float((radii != radii0).float().mean()) < 1e-3
+        d = (img - img0).abs()
+        assert float(d.mean()) < 1e-6 and float((d > 1e-4).float().mean()) < 1e-3, (name, float(d.max()))
+        for a, b in zip(grads, grads0):
+            assert float((a - b).abs().max()) <= 2e-3 * max(1e-12, float(b.abs().max())), name
+
+
+def test_clones_with_identical_depth_keep_index_order():
+    """Densification clones share xyz (scene/gaussian_model.py:555): equal (tile, depth) keys must
+    resolve to ascending Gaussian index exactly like cub's stable sort."""
+    _need_gpu()
+    from test_parity_gpu import check_forward, check_grads
+    base = gsr_scene.make_scene(800, -2.8, sh_degree=1, seed=31)
+    rep = lambda t: torch.cat([t, t[:300], t[100:250]]).contiguous()
+    g = torch.Generator().manual_seed(1)
+    scene = gsr_scene.Scene(rep(base.means3D), rep(base.scales) * (0.5 + torch.rand(1250, 3, generator=g)),
+                            rep(base.rotations), rep(base.opacities), rep(base.shs) + 0.1 * torch.randn(1250, 4, 3, generator=g), base.bg)
+    cam = gsr_scene.make_camera(160, 96)
+    o = util.oracle_forward(scene, cam, 1)
+    keys = o["keys"]
+    assert int((keys[1:] == keys[:-1]).sum()) > 100, "fixture must contain equal keys"
+    dpix = util.fragile_free_dpix(o, cam)
+    h = util.hip_forward_backward(scene, cam, 1, dpix)
+    check_forward(h, o, cam)
+    check_grads(h, o, dpix, ["dL_dmeans3D", "dL_dopacity", "dL_dsh", "dL_dscales", "dL_drotations"])
+
+
+def test_opacity_zero_and_one():
+    _need_gpu()
+    from test_parity_gpu import check_forward, check_grads
+    scene = gsr_scene.make_scene(1500, -2.8, sh_degree=0, seed=41)
+    op = scene.opacities.clone()
+    op[::3] = 0.0      # never reaches 1/255: still binned (parity of point_list), contributes nothing
+    op[1::3] = 1.0     # alpha clamps at 0.99 near the centre
+    scene = scene._replace(opacities=op)
+    cam = gsr_scene.make_camera(128, 80)
+    o = util.oracle_forward(scene, cam, 0)
+    dpix = util.fragile_free_dpix(o, cam)
+    h = util.hip_forward_backward(scene, cam, 0, dpix)
+    check_forward(h, o, cam)
+    check_grads(h, o, dpix, ["dL_dmeans3D", "dL_dopacity", "dL_dsh", "dL_dscales", "dL_drotations"])
+    assert np.all(h["grads"]["dL_dopacity"][::3] == 0), "a splat that never reaches alpha 1/255 gets no gradient at all"
+
+
+def test_debug_mode_and_snapshot_dump(tmp_path, monkeypatch):
+    _need_gpu()
+    from diff_gaussian_rasterization import GaussianRasterizer
+    dev = torch.device("cuda:0")
+    scene = gsr_scene.make_scene(500, -3.0, sh_degree=0, seed=5)
+    cam = gsr_scene.make_camera(64, 48)
+    o = util.oracle_forward(scene, cam, 0)
+    dpix = util.fragile_free_dpix(o, cam)
+    h = util.hip_forward_backward(scene, cam, 0, dpix, debug=True)  # sync + check after every stage
+    np.testing.assert_array_equal(h["radii"], o["radii"])
+    # a failing forward in debug mode writes snapshot_fw.dump into the cwd (reference __init__.py:87-94)
+    monkeypatch.chdir(tmp_path)
+    cam2 = gsr_scene.ring_camera(32, 32, 1, 8, radius=1.0)
+    r = GaussianRasterizer(util.hip_settings(scene, cam2, 0, dev, prefiltered=True, debug=True))
+    m = scene.means3D.to(dev)
+    with pytest.raises(RuntimeError, match="filtered although prefiltered"):
+        r(means3D=m, means2D=m, opacities=scene.opacities.to(dev), shs=scene.shs.to(dev), scales=scene.scales.to(dev),
+          rotations=scene.rotations.to(dev))
+    assert os.path.exists(tmp_path / "snapshot_fw.dump")
+    args = torch.load(tmp_path / "snapshot_fw.dump", weights_only=False)  # our own file, written a moment ago
+    assert len(args) == 19 and torch.equal(args[1], scene.means3D)
