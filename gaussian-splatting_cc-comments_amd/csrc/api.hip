@@ -11,6 +11,8 @@
 
 #include "gsr_internal.h"
 
+#define GSR_MAX_DEVICES 64
+
 // ---- errors ------------------------------------------------------------------------------------
 static thread_local char g_err[512] = "";
 
@@ -290,12 +292,18 @@ extern "C" int gsr_forward_preprocess(int P, int D, int M, int width, int height
 
 	// read num_rendered back; the per-Gaussian half of the sort is enqueued behind the copy and keeps
 	// the GPU busy while the host waits on the event, allocates the binning buffer and launches stage 2
-	static thread_local uint32_t* status_host = nullptr;  // pinned, reused
-	static thread_local hipEvent_t ev = nullptr;
-	if (!status_host) {
-		if ((rc = gsr_check_hip(hipHostMalloc((void**)&status_host, 16, hipHostMallocDefault), "hipHostMalloc"))) return rc;
-		if ((rc = gsr_check_hip(hipEventCreateWithFlags(&ev, hipEventDisableTiming), "hipEventCreate"))) return rc;
+	// pinned landing buffer + event, created once per (thread, device) and reused
+	static thread_local uint32_t* status_host_of[GSR_MAX_DEVICES] = {nullptr};
+	static thread_local hipEvent_t event_of[GSR_MAX_DEVICES] = {nullptr};
+	int device = 0;
+	if ((rc = gsr_check_hip(hipGetDevice(&device), "hipGetDevice"))) return rc;
+	if (device < 0 || device >= GSR_MAX_DEVICES) return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "device index %d not supported", device);
+	if (!status_host_of[device]) {
+		if ((rc = gsr_check_hip(hipHostMalloc((void**)&status_host_of[device], 16, hipHostMallocDefault), "hipHostMalloc"))) return rc;
+		if ((rc = gsr_check_hip(hipEventCreateWithFlags(&event_of[device], hipEventDisableTiming), "hipEventCreate"))) return rc;
 	}
+	uint32_t* status_host = status_host_of[device];
+	hipEvent_t ev = event_of[device];
 	if ((rc = gsr_check_hip(hipMemcpyAsync(status_host, a.g.status, 8, hipMemcpyDeviceToHost, s), "hipMemcpyAsync(num_rendered)"))) return rc;
 	if ((rc = gsr_check_hip(hipEventRecord(ev, s), "hipEventRecord"))) return rc;
 	{

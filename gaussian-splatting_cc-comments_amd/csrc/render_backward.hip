@@ -21,7 +21,7 @@ __global__ void __launch_bounds__(64 * GSR_WAVES_PER_WG, 1) gsr_render_backward_
 	int W, int H, int gx, int ntiles, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
 	const GsrSplat* __restrict__ splat, const float* __restrict__ bg, const float* __restrict__ final_Ts,
 	const uint32_t* __restrict__ n_contrib, const uint32_t* __restrict__ tile_max_contrib,
-	const float* __restrict__ dL_dpixels, GsrGradSlot* __restrict__ slots, uint8_t* __restrict__ slot_valid)
+	const float* __restrict__ dL_dpixels, GsrGradSlot* __restrict__ slots, uint8_t* __restrict__ slot_valid, int cull)
 {
 	__shared__ float4 s_rec[GSR_WAVES_PER_WG][3][64];
 	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -89,7 +89,7 @@ __global__ void __launch_bounds__(64 * GSR_WAVES_PER_WG, 1) gsr_render_backward_
 	const int out_index = gsr_bfly_index(lane >> 3);  // which of v[0..7] this lane's 8-lane group ends up holding
 
 	for (int base = 0; base < n; base += 64) {
-		const uint32_t bands = (base + lane < n) ? gsr_tile_band_mask(ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, x0f, y0f) : 0u;
+		const uint32_t bands = (base + lane < n) ? (cull ? gsr_tile_band_mask(ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, x0f, y0f) : 0xFu) : 0u;
 		const bool keep = bands != 0u;
 		const unsigned long long mask = __ballot(keep);
 		const int cnt = __popcll(mask);
@@ -206,5 +206,5 @@ void gsr_launch_render_backward(int W, int H, GsrImage img, const uint32_t* poin
 	const int nwg = (ntiles + GSR_WAVES_PER_WG - 1) / GSR_WAVES_PER_WG;
 	hipLaunchKernelGGL(gsr_render_backward_wave_kernel, dim3(nwg), dim3(64 * GSR_WAVES_PER_WG), 0, s, W, H, gx, ntiles,
 	                   img.ranges, point_list, splat, bg, img.final_T, img.n_contrib, img.tile_max_contrib, dL_dpix,
-	                   slots, slot_valid);
+	                   slots, slot_valid, gsr_culling_enabled());
 }

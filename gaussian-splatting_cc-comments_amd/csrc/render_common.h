@@ -8,6 +8,16 @@
 #pragma once
 #include "gsr_internal.h"
 
+#include <stdlib.h>
+// Diagnostic knob: GSR_NO_CULL=1 disables the exact-result-preserving culling (every instance of
+// the reference's tile list is evaluated on every band), to bisect a suspected culling error.
+static inline int gsr_culling_enabled()
+{
+	static int v = -1;
+	if (v < 0) { const char* e = getenv("GSR_NO_CULL"); v = (e && e[0] == '1') ? 0 : 1; }
+	return v;
+}
+
 #define GSR_WAVES_PER_WG 1
 #define GSR_PIX_PER_LANE 4
 
@@ -15,10 +25,11 @@
 // q = a dx^2 + 2 b dx dy + c dy^2 can reach 1/255 inside a pixel rectangle only if the minimum of
 // q over the rectangle is <= 2 ln(255 o).  The minimum of the convex quadratic over a rectangle is
 // 0 when the centre lies inside it and otherwise sits on one of the four edges, where it has a
-// closed form.  A slack of 1e-3 in q (5e-4 relative in alpha, orders of magnitude above the fp32
-// rounding of `power`) keeps the test conservative: an instance that the reference would blend
-// into any pixel of the rectangle is never dropped, and dropped instances contribute exactly
-// nothing in the reference either (forward.cu:438-447, backward.cu:521-531).
+// closed form.  The test is kept conservative by a slack of 1e-3 in q (5e-4 relative in alpha) plus
+// 1e-5 of the magnitude of the terms that cancel in q (for a giant elongated splat far from its
+// centre they are O(1e6) and their fp32 sum is only good to ~1): an instance that the reference
+// would blend into any pixel of the rectangle is never dropped, and dropped instances contribute
+// exactly nothing in the reference either (forward.cu:438-447, backward.cu:521-531).
 // Returns a 4-bit mask: bit k set = the instance may reach the band of pixel rows 4k..4k+3 of the
 // 16x16 tile at (x0, y0) (the rows owned by pixel slot k of every lane); 0 = drop the instance.
 __device__ __forceinline__ uint32_t gsr_tile_band_mask(float mx, float my, float a, float b, float c, float op, float x0,
@@ -36,14 +47,17 @@ __device__ __forceinline__ uint32_t gsr_tile_band_mask(float mx, float my, float
 		const float dyl = my - (y0 + 4.0f * k + 3.0f), dyh = my - (y0 + 4.0f * k);
 		float q = 0.f;
 		if (!(x_in && dyl <= 0.f && dyh >= 0.f)) {
+			// q(X, Y) minus a bound on its own rounding error
+#define GSR_Q(X, Y) ((a * (X) * (X) + 2.f * b * (X) * (Y) + c * (Y) * (Y)) - 1e-5f * (a * (X) * (X) + fabsf(2.f * b * (X) * (Y)) + c * (Y) * (Y)))
 			float X = dxl, Y = fminf(dyh, fmaxf(dyl, nbc * X));
-			q = a * X * X + 2.f * b * X * Y + c * Y * Y;
+			q = GSR_Q(X, Y);
 			X = dxh; Y = fminf(dyh, fmaxf(dyl, nbc * X));
-			q = fminf(q, a * X * X + 2.f * b * X * Y + c * Y * Y);
+			q = fminf(q, GSR_Q(X, Y));
 			Y = dyl; X = fminf(dxh, fmaxf(dxl, nba * Y));
-			q = fminf(q, a * X * X + 2.f * b * X * Y + c * Y * Y);
+			q = fminf(q, GSR_Q(X, Y));
 			Y = dyh; X = fminf(dxh, fmaxf(dxl, nba * Y));
-			q = fminf(q, a * X * X + 2.f * b * X * Y + c * Y * Y);
+			q = fminf(q, GSR_Q(X, Y));
+#undef GSR_Q
 		}
 		if (!(q > thr)) mask |= 1u << k;  // NaN -> keep
 	}

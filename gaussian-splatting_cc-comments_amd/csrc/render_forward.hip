@@ -20,7 +20,7 @@
 __global__ void __launch_bounds__(64 * GSR_WAVES_PER_WG) gsr_render_forward_wave_kernel(
 	int W, int H, int gx, int ntiles, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
 	const GsrSplat* __restrict__ splat, const float* __restrict__ bg, float* __restrict__ final_T,
-	uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ tile_max_contrib, float* __restrict__ out_color)
+	uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ tile_max_contrib, float* __restrict__ out_color, int cull)
 {
 	__shared__ float4 s_rec[GSR_WAVES_PER_WG][3][64];
 	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -61,7 +61,7 @@ __global__ void __launch_bounds__(64 * GSR_WAVES_PER_WG) gsr_render_forward_wave
 
 	for (int base = 0; base < n; base += 64) {
 		if (__ballot(fmaxf(fmaxf(Trun[0], Trun[1]), fmaxf(Trun[2], Trun[3])) > 0.f) == 0ull) break;
-		const uint32_t bands = (base + lane < n) ? gsr_tile_band_mask(ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, x0f, y0f) : 0u;
+		const uint32_t bands = (base + lane < n) ? (cull ? gsr_tile_band_mask(ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, x0f, y0f) : 0xFu) : 0u;
 		const bool keep = bands != 0u;
 		const unsigned long long mask = __ballot(keep);
 		const int cnt = __popcll(mask);
@@ -139,5 +139,6 @@ void gsr_launch_render_forward(int W, int H, GsrImage img, const uint32_t* point
 	const int ntiles = gx * gy;
 	const int nwg = (ntiles + GSR_WAVES_PER_WG - 1) / GSR_WAVES_PER_WG;
 	hipLaunchKernelGGL(gsr_render_forward_wave_kernel, dim3(nwg), dim3(64 * GSR_WAVES_PER_WG), 0, s, W, H, gx, ntiles,
-	                   img.ranges, point_list, splat, bg, img.final_T, img.n_contrib, img.tile_max_contrib, out_color);
+	                   img.ranges, point_list, splat, bg, img.final_T, img.n_contrib, img.tile_max_contrib, out_color,
+	                   gsr_culling_enabled());
 }

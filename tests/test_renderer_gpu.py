@@ -113,3 +113,24 @@ def test_debug_mode_and_snapshot_dump(tmp_path, monkeypatch):
     assert os.path.exists(tmp_path / "snapshot_fw.dump")
     args = torch.load(tmp_path / "snapshot_fw.dump", weights_only=False)  # our own file, written a moment ago
     assert len(args) == 19 and torch.equal(args[1], scene.means3D)
+
+
+def test_giant_elongated_splats_are_never_culled_wrongly():
+    """Needle-shaped splats hundreds of pixels long: the quadratic form evaluated by the culling test
+    cancels by many orders of magnitude far from the centre; the result must still match the oracle."""
+    _need_gpu()
+    from test_parity_gpu import check_forward, check_grads
+    g = torch.Generator().manual_seed(77)
+    P = 300
+    base = gsr_scene.make_scene(P, -3.0, sh_degree=0, seed=77)
+    scales = base.scales.clone()
+    scales[:, 0] = torch.exp(torch.randn(P, generator=g) * 0.5 + 0.3)      # ~1.3 world units along one axis
+    scales[:, 1:] = torch.exp(torch.randn(P, 2, generator=g) * 0.3 - 5.0)  # ~0.007 across
+    scene = base._replace(scales=scales.contiguous(), opacities=torch.full((P, 1), 0.95))
+    cam = gsr_scene.make_camera(640, 360)
+    o = util.oracle_forward(scene, cam, 0)
+    assert int(o["radii"].max()) > 300
+    dpix = util.fragile_free_dpix(o, cam)
+    h = util.hip_forward_backward(scene, cam, 0, dpix)
+    check_forward(h, o, cam)
+    check_grads(h, o, dpix, ["dL_dmeans3D", "dL_dopacity", "dL_dsh", "dL_dscales", "dL_drotations"])
