@@ -66,3 +66,36 @@ def all_reduce_max_radii(radii: torch.Tensor, group: Optional[dist.ProcessGroup]
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.all_reduce(out, op=dist.ReduceOp.MAX, group=group)
     return out
+
+
+class DensificationStats:
+    """The training-loop statistics that consume the rasterizer's side outputs
+    (train.py:157-159, scene/gaussian_model.py:599-602), view-parallel:
+
+        max_radii2D[vis] = max(max_radii2D[vis], radii[vis])                      per view
+        xyz_gradient_accum[vis] += || viewspace_points.grad[vis, :2] ||           per view
+        denom[vis] += 1                                                           per view
+
+    With one view per rank, the N views of a step are folded with ONE int32 MAX all-reduce (radii,
+    0 where culled) and ONE float SUM all-reduce of a (P,2) tensor [norm * vis, vis]; the result is
+    what the reference would hold after applying its update once per view, in any order.
+    """
+
+    def __init__(self, num_points: int, device=None):
+        self.max_radii2D = torch.zeros(num_points, device=device)
+        self.xyz_gradient_accum = torch.zeros(num_points, 1, device=device)
+        self.denom = torch.zeros(num_points, 1, device=device)
+
+    @torch.no_grad()
+    def update(self, viewspace_grad: torch.Tensor, radii: torch.Tensor, group: Optional[dist.ProcessGroup] = None):
+        vis = radii > 0
+        r = torch.where(vis, radii, torch.zeros_like(radii))
+        s = torch.zeros(radii.shape[0], 2, device=radii.device, dtype=viewspace_grad.dtype)
+        s[:, 0] = torch.norm(viewspace_grad[:, :2], dim=-1) * vis
+        s[:, 1] = vis.to(s.dtype)
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            dist.all_reduce(r, op=dist.ReduceOp.MAX, group=group)
+            dist.all_reduce(s, op=dist.ReduceOp.SUM, group=group)
+        self.max_radii2D = torch.max(self.max_radii2D, r.to(self.max_radii2D.dtype))
+        self.xyz_gradient_accum += s[:, 0:1]
+        self.denom += s[:, 1:2]

@@ -51,3 +51,36 @@ def _worker(rank, world, port, P):
 
 def test_gradient_bucket_all_reduce_gloo_world2():
     mp.spawn(_worker, args=(2, _free_port(), 257), nprocs=2, join=True)
+
+
+def _stats_worker(rank, world, port, P):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        def view(r):  # what rank r's view produced (same on every rank, seeded by r)
+            g = torch.Generator().manual_seed(100 + r)
+            radii = (torch.rand(P, generator=g) * 40).to(torch.int32) * (torch.rand(P, generator=g) > 0.3)
+            grad = torch.randn(P, 3, generator=g)
+            return grad, radii.to(torch.int32)
+        stats = view_parallel.DensificationStats(P)
+        for step in range(2):
+            grad, radii = view(rank + world * step)
+            stats.update(grad, radii)
+        # the reference's bookkeeping applied once per view, sequentially (train.py:157-159, gaussian_model.py:599-602)
+        max_radii2D, accum, denom = torch.zeros(P), torch.zeros(P, 1), torch.zeros(P, 1)
+        for v in range(2 * world):
+            grad, radii = view(v)
+            vis = radii > 0
+            max_radii2D[vis] = torch.max(max_radii2D[vis], radii[vis].float())
+            accum[vis] += torch.norm(grad[vis, :2], dim=-1, keepdim=True)
+            denom[vis] += 1
+        assert torch.equal(stats.max_radii2D, max_radii2D)
+        assert torch.equal(stats.denom, denom)
+        assert torch.allclose(stats.xyz_gradient_accum, accum, rtol=1e-6, atol=1e-6)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_densification_stats_match_per_view_updates_gloo_world2():
+    mp.spawn(_stats_worker, args=(2, _free_port(), 513), nprocs=2, join=True)
