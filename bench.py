@@ -100,6 +100,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="C3", choices=list(gsr_scene.CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sh-exchange", default="compact", choices=["compact", "allreduce"],
+                    help="N > 1: 'compact' all-gathers 3 floats/Gaussian/view and rebuilds the summed SH gradient "
+                         "locally (view_parallel.exchange_sh_gradient); 'allreduce' sums all 59 floats/Gaussian")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -138,18 +141,26 @@ def main():
     dpix = to(torch.randn(3, H, W, generator=g))
     state = {}
     bucket = None
+    compact = world > 1 and args.sh_exchange == "compact"
     if world > 1:
         import view_parallel
-        bucket = view_parallel.GradientBucket(params.values())  # one flat 59-floats-per-Gaussian RCCL all-reduce
+        # one flat RCCL all-reduce: all 59 floats/Gaussian, or the 11 non-SH ones when SH goes the compact way
+        bucket = view_parallel.GradientBucket([v for k, v in params.items() if not (compact and k == "shs")])
 
     def step():
         for p in params.values():
             p.grad = None
         means2D = torch.zeros_like(params["means3D"], requires_grad=True)  # gaussian_renderer/__init__.py:37
         color, radii = rasterizer(means3D=params["means3D"], means2D=means2D, **{k: v for k, v in params.items() if k != "means3D"})
-        color.backward(dpix)
-        if world > 1:  # view-parallel: sum the 59 floats/Gaussian of parameter gradients over ranks
+        if compact:
+            with view_parallel.skip_sh_gradient() as side:
+                color.backward(dpix)
+            params["shs"].grad = view_parallel.exchange_sh_gradient(params["means3D"], settings.campos, side.dL_dRGB, D, M)
             bucket.all_reduce()
+        else:
+            color.backward(dpix)
+            if world > 1:  # view-parallel: sum the 59 floats/Gaussian of parameter gradients over ranks
+                bucket.all_reduce()
         state["color"], state["radii"] = color, radii
 
     for _ in range(args.warmup):
@@ -225,7 +236,8 @@ def main():
                    higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
                    config=dict(workload=f"{args.config}: {P} Gaussians, SH deg {D}, {W}x{H}, mu={mu}, seed 0",
                                P=P, V=V, R=R, R_staged_fwd=Rp, views_per_step=world,
-                               parallelism=f"view-parallel x{world}" if world > 1 else "single view"),
+                               parallelism=(f"view-parallel x{world}, SH gradient exchange: {args.sh_exchange}"
+                                            if world > 1 else "single view")),
                    roofline=roofline, kernels=kern)
         if world == 1 and not args.no_cpu_baseline:
             import numpy as np

@@ -391,7 +391,7 @@ extern "C" int gsr_backward(int P, int D, int M, int64_t R, int width, int heigh
 	if (P == 0) return GSR_OK;
 	if (!background || !means3D || !viewmatrix || !projmatrix || !radii || !geometry || !image || !dL_dpix ||
 	    !dL_dmean2D || !dL_dconic || !dL_dopacity || !dL_dcolor || !dL_dmean3D || !dL_dcov3D || !dL_dscale || !dL_drot ||
-	    (R > 0 && (!binning || !scratch)) || (M > 0 && !dL_dsh))
+	    (R > 0 && (!binning || !scratch)))
 		return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "gsr_backward: required pointer is NULL");
 	if (!aligned16(geometry) || !aligned16(image) || !aligned16(binning) || !aligned16(scratch))
 		return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "state buffers must be 16-byte aligned");
@@ -427,6 +427,19 @@ extern "C" int gsr_backward(int P, int D, int M, int64_t R, int width, int heigh
 		gsr_launch_gaussian_backward(a, s);
 	}
 	return gsr_stage_done(s, debug, "gaussian_backward");
+}
+
+extern "C" int gsr_sh_grad_from_views(int P, int D, int M, int V, const float* means3D, const float* cam_pos,
+                                      const float* dL_dRGB, float* dL_dsh, void* stream)
+{
+	g_err[0] = 0;
+	if (P < 0 || V < 0 || D < 0 || D > 3 || M <= 0 || M > 16 || (D + 1) * (D + 1) > M)
+		return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "gsr_sh_grad_from_views: bad sizes (P %d, V %d, D %d, M %d)", P, V, D, M);
+	if (P == 0) return GSR_OK;
+	if (!means3D || !dL_dsh || (V > 0 && (!cam_pos || !dL_dRGB)))
+		return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "gsr_sh_grad_from_views: NULL pointer");
+	gsr_launch_sh_grad_from_views(P, D, M, V, means3D, cam_pos, dL_dRGB, dL_dsh, (hipStream_t)stream);
+	return gsr_stage_done((hipStream_t)stream, 0, "sh_grad_from_views");
 }
 
 extern "C" int gsr_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,

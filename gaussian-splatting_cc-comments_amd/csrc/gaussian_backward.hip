@@ -18,49 +18,72 @@ __device__ __forceinline__ GsrVec3 gsr_dnormvdv(GsrVec3 v, GsrVec3 dv)  // auxil
 	return r;
 }
 
-// backward.cu:20-139; writes dL_dsh rows [0, (D+1)^2) and zeros the rest up to M
+// dRGB/dsh_k for k < (deg+1)^2: the SH basis at direction (x,y,z), expressions of backward.cu:45-96
+__device__ __forceinline__ void gsr_sh_basis(int deg, float x, float y, float z, float* b)
+{
+	b[0] = GSR_SH_C0;
+	if (deg > 0) {
+		b[1] = -GSR_SH_C1 * y;
+		b[2] = GSR_SH_C1 * z;
+		b[3] = -GSR_SH_C1 * x;
+		if (deg > 1) {
+			float xx = x * x, yy = y * y, zz = z * z;
+			float xy = x * y, yz = y * z, xz = x * z;
+			b[4] = GSR_SH_C2[0] * xy;
+			b[5] = GSR_SH_C2[1] * yz;
+			b[6] = GSR_SH_C2[2] * (2.f * zz - xx - yy);
+			b[7] = GSR_SH_C2[3] * xz;
+			b[8] = GSR_SH_C2[4] * (xx - yy);
+			if (deg > 2) {
+				b[9] = GSR_SH_C3[0] * y * (3.f * xx - yy);
+				b[10] = GSR_SH_C3[1] * xy * z;
+				b[11] = GSR_SH_C3[2] * y * (4.f * zz - xx - yy);
+				b[12] = GSR_SH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy);
+				b[13] = GSR_SH_C3[4] * x * (4.f * zz - xx - yy);
+				b[14] = GSR_SH_C3[5] * z * (xx - yy);
+				b[15] = GSR_SH_C3[6] * x * (xx - 3.f * yy);
+			}
+		}
+	}
+}
+
+// backward.cu:20-139.  dL_dRGB = dL_dcolor with clamped channels zeroed (returned in dL_dRGB_out).
+// write_dsh: writes dL_dsh rows [0, (D+1)^2) and zeros the rest up to M; otherwise only the
+// view-direction term of dL_dmean is produced (view-parallel mode, see gsr_sh_grad_from_views).
 __device__ __forceinline__ void gsr_sh_backward(int deg, int M, GsrVec3 pos, const float* campos, const float* sh,
                                                 uint8_t clamp_bits, const float* dL_dcolor, float* dL_dmean,
-                                                float* dL_dsh)
+                                                float* dL_dsh, bool write_dsh, float* dL_dRGB_out)
 {
 	GsrVec3 dir_orig = {pos.x - campos[0], pos.y - campos[1], pos.z - campos[2]};
 	float len = sqrtf(dir_orig.x * dir_orig.x + dir_orig.y * dir_orig.y + dir_orig.z * dir_orig.z);
 	float x = dir_orig.x / len, y = dir_orig.y / len, z = dir_orig.z / len;
 	float dd0 = 0.f, dd1 = 0.f, dd2 = 0.f;
 	const int used = (deg + 1) * (deg + 1);
+	float basis[16];
+	gsr_sh_basis(deg, x, y, z, basis);
 #pragma unroll
 	for (int ch = 0; ch < 3; ch++) {
 #define SH(k) sh[(k) * 3 + ch]
-#define DSH(k) dL_dsh[(k) * 3 + ch]
 		const float g = dL_dcolor[ch] * (((clamp_bits >> ch) & 1) ? 0.f : 1.f);
+		dL_dRGB_out[ch] = g;
 		float dRGBdx = 0, dRGBdy = 0, dRGBdz = 0;
-		DSH(0) = GSR_SH_C0 * g;
+		if (write_dsh) {
+#pragma unroll
+			for (int k = 0; k < 16; k++)
+				if (k < used) dL_dsh[k * 3 + ch] = basis[k] * g;
+			for (int k = used; k < M; k++) dL_dsh[k * 3 + ch] = 0.f;
+		}
 		if (deg > 0) {
-			DSH(1) = (-GSR_SH_C1 * y) * g;
-			DSH(2) = (GSR_SH_C1 * z) * g;
-			DSH(3) = (-GSR_SH_C1 * x) * g;
 			dRGBdx = -GSR_SH_C1 * SH(3);
 			dRGBdy = -GSR_SH_C1 * SH(1);
 			dRGBdz = GSR_SH_C1 * SH(2);
 			if (deg > 1) {
 				float xx = x * x, yy = y * y, zz = z * z;
 				float xy = x * y, yz = y * z, xz = x * z;
-				DSH(4) = (GSR_SH_C2[0] * xy) * g;
-				DSH(5) = (GSR_SH_C2[1] * yz) * g;
-				DSH(6) = (GSR_SH_C2[2] * (2.f * zz - xx - yy)) * g;
-				DSH(7) = (GSR_SH_C2[3] * xz) * g;
-				DSH(8) = (GSR_SH_C2[4] * (xx - yy)) * g;
 				dRGBdx += GSR_SH_C2[0] * y * SH(4) + GSR_SH_C2[2] * 2.f * -x * SH(6) + GSR_SH_C2[3] * z * SH(7) + GSR_SH_C2[4] * 2.f * x * SH(8);
 				dRGBdy += GSR_SH_C2[0] * x * SH(4) + GSR_SH_C2[1] * z * SH(5) + GSR_SH_C2[2] * 2.f * -y * SH(6) + GSR_SH_C2[4] * 2.f * -y * SH(8);
 				dRGBdz += GSR_SH_C2[1] * y * SH(5) + GSR_SH_C2[2] * 2.f * 2.f * z * SH(6) + GSR_SH_C2[3] * x * SH(7);
 				if (deg > 2) {
-					DSH(9) = (GSR_SH_C3[0] * y * (3.f * xx - yy)) * g;
-					DSH(10) = (GSR_SH_C3[1] * xy * z) * g;
-					DSH(11) = (GSR_SH_C3[2] * y * (4.f * zz - xx - yy)) * g;
-					DSH(12) = (GSR_SH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy)) * g;
-					DSH(13) = (GSR_SH_C3[4] * x * (4.f * zz - xx - yy)) * g;
-					DSH(14) = (GSR_SH_C3[5] * z * (xx - yy)) * g;
-					DSH(15) = (GSR_SH_C3[6] * x * (xx - 3.f * yy)) * g;
 					dRGBdx += (GSR_SH_C3[0] * SH(9) * 3.f * 2.f * xy + GSR_SH_C3[1] * SH(10) * yz + GSR_SH_C3[2] * SH(11) * -2.f * xy +
 					           GSR_SH_C3[3] * SH(12) * -3.f * 2.f * xz + GSR_SH_C3[4] * SH(13) * (-3.f * xx + 4.f * zz - yy) +
 					           GSR_SH_C3[5] * SH(14) * 2.f * xz + GSR_SH_C3[6] * SH(15) * 3.f * (xx - yy));
@@ -74,9 +97,7 @@ __device__ __forceinline__ void gsr_sh_backward(int deg, int M, GsrVec3 pos, con
 				}
 			}
 		}
-		for (int k = used; k < M; k++) DSH(k) = 0.f;
 #undef SH
-#undef DSH
 		dd0 += dRGBdx * g; dd1 += dRGBdy * g; dd2 += dRGBdz * g;
 	}
 	GsrVec3 ddir = {dd0, dd1, dd2};
@@ -140,7 +161,7 @@ __device__ __forceinline__ void gsr_add_slot(const GsrGradSlot* __restrict__ slo
 
 #define GSR_SH_ROW4 13  // LDS row stride in float4: 12 used + 1 pad -> conflict-free ds_read/write_b128 per row
 
-__global__ void __launch_bounds__(256) gsr_gaussian_backward_kernel(GsrGaussianBackwardArgs a, int sh_via_lds)
+__global__ void __launch_bounds__(256) gsr_gaussian_backward_kernel(GsrGaussianBackwardArgs a, int sh_via_lds, int skip_dsh)
 {
 	__shared__ float4 s_sh[4][64 * GSR_SH_ROW4];
 	const int idx = blockIdx.x * 256 + threadIdx.x;
@@ -194,6 +215,7 @@ __global__ void __launch_bounds__(256) gsr_gaussian_backward_kernel(GsrGaussianB
 	float dmean3D[3] = {0.f, 0.f, 0.f}, dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 	float dscale[3] = {0.f, 0.f, 0.f}, drot[4] = {0.f, 0.f, 0.f, 0.f};
 	float* dsh_global = (a.dL_dsh && in_range) ? a.dL_dsh + (size_t)idx * M * 3 : nullptr;
+	float dRGB[3] = {0.f, 0.f, 0.f};  // dL/dcolor with the channels clamped by the forward zeroed
 	float* my_row = reinterpret_cast<float*>(&s_sh[wave][lane * GSR_SH_ROW4]);
 
 	if (visible) {
@@ -276,9 +298,10 @@ __global__ void __launch_bounds__(256) gsr_gaussian_backward_kernel(GsrGaussianB
 					const float4 v = s_sh[wave][lane * GSR_SH_ROW4 + j];
 					shv[4 * j] = v.x; shv[4 * j + 1] = v.y; shv[4 * j + 2] = v.z; shv[4 * j + 3] = v.w;
 				}
-				gsr_sh_backward(a.D, M, mean, a.cam_pos, shv, a.g.clamped[idx], dcolor, dmean3D, my_row);
+				gsr_sh_backward(a.D, M, mean, a.cam_pos, shv, a.g.clamped[idx], dcolor, dmean3D, my_row, !skip_dsh, dRGB);
 			} else {
-				gsr_sh_backward(a.D, M, mean, a.cam_pos, a.shs + (size_t)idx * M * 3, a.g.clamped[idx], dcolor, dmean3D, dsh_global);
+				gsr_sh_backward(a.D, M, mean, a.cam_pos, a.shs + (size_t)idx * M * 3, a.g.clamped[idx], dcolor, dmean3D, dsh_global,
+				                !skip_dsh, dRGB);
 			}
 		}
 		if (a.scales)
@@ -286,7 +309,10 @@ __global__ void __launch_bounds__(256) gsr_gaussian_backward_kernel(GsrGaussianB
 	}
 
 	// ---- dL_dsh: zeros for culled Gaussians; coalesced write-out of the wave's block ----
-	if (sh_via_lds) {
+	if (skip_dsh) {
+		// view-parallel mode: no SH gradient here; dL_dcolor carries the clamp-masked dL/dRGB instead
+		dcolor[0] = dRGB[0]; dcolor[1] = dRGB[1]; dcolor[2] = dRGB[2];
+	} else if (sh_via_lds) {
 		if (!visible) {
 #pragma unroll
 			for (int j = 0; j < 12; j++) s_sh[wave][lane * GSR_SH_ROW4 + j] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -325,6 +351,75 @@ __global__ void __launch_bounds__(256) gsr_gaussian_backward_kernel(GsrGaussianB
 void gsr_launch_gaussian_backward(const GsrGaussianBackwardArgs& a, hipStream_t s)
 {
 	// LDS-transposed SH path: the flagship layout (16 coefficients) with 16-byte aligned tensors
-	const int sh_via_lds = (a.shs && a.dL_dsh && a.M == 16 && (((uintptr_t)a.shs | (uintptr_t)a.dL_dsh) & 15u) == 0) ? 1 : 0;
-	hipLaunchKernelGGL(gsr_gaussian_backward_kernel, dim3((a.P + 255) / 256), dim3(256), 0, s, a, sh_via_lds);
+	const int skip_dsh = (a.shs && !a.dL_dsh) ? 1 : 0;  // view-parallel mode (include/gsr.h)
+	const int sh_via_lds = (a.shs && a.M == 16 && ((uintptr_t)a.shs & 15u) == 0 && (skip_dsh || ((uintptr_t)a.dL_dsh & 15u) == 0)) ? 1 : 0;
+	hipLaunchKernelGGL(gsr_gaussian_backward_kernel, dim3((a.P + 255) / 256), dim3(256), 0, s, a, sh_via_lds, skip_dsh);
+}
+
+// ---- view-parallel SH gradient (no reference counterpart) ------------------------------
+// dL/dsh of ONE view is the outer product basis(dir) x dL/dRGB per Gaussian (backward.cu:45-96), so the
+// SH gradient summed over V views can be rebuilt from V x 3 floats per Gaussian (+ V camera
+// positions) instead of exchanging 3*M floats per Gaussian: ranks all-gather the clamp-masked
+// dL/dRGB of their views (12 B per Gaussian per view) and every rank runs this kernel.  Views are
+// added in index order with the products rounded first -- the sum a fixed-order all-reduce of the
+// per-view gradients would give.
+__global__ void __launch_bounds__(256) gsr_sh_grad_from_views_kernel(int P, int D, int M, int V, const float* __restrict__ means3D,
+                                                                      const float* __restrict__ cam_pos,
+                                                                      const float* __restrict__ dL_dRGB, float* __restrict__ dL_dsh,
+                                                                      int via_lds)
+{
+	__shared__ float4 s_sh[4][64 * GSR_SH_ROW4];
+	const int idx = blockIdx.x * 256 + threadIdx.x;
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const bool in_range = idx < P;
+	const int used = (D + 1) * (D + 1);
+	float acc[48];
+#pragma unroll
+	for (int i = 0; i < 48; i++) acc[i] = 0.f;
+	if (in_range) {
+		const float mx = means3D[3 * idx], my = means3D[3 * idx + 1], mz = means3D[3 * idx + 2];
+		for (int v = 0; v < V; v++) {
+			const float* g = dL_dRGB + ((size_t)v * P + idx) * 3;
+			const float g0 = g[0], g1 = g[1], g2 = g[2];
+			if (g0 == 0.f && g1 == 0.f && g2 == 0.f) continue;  // culled in this view (or no gradient): adds exact zeros
+			const float dx = mx - cam_pos[3 * v], dy = my - cam_pos[3 * v + 1], dz = mz - cam_pos[3 * v + 2];
+			const float len = sqrtf(dx * dx + dy * dy + dz * dz);
+			float basis[16];
+			gsr_sh_basis(D, dx / len, dy / len, dz / len, basis);
+#pragma unroll
+			for (int k = 0; k < 16; k++)
+				if (k < used) {
+					acc[3 * k] += basis[k] * g0;
+					acc[3 * k + 1] += basis[k] * g1;
+					acc[3 * k + 2] += basis[k] * g2;
+				}
+		}
+	}
+	if (via_lds) {  // M == 16: coalesced float4 stream through an LDS transpose
+		const int wave_first = blockIdx.x * 256 + wave * 64;
+		const int nrows = min(64, P - wave_first);
+#pragma unroll
+		for (int j = 0; j < 12; j++)
+			s_sh[wave][lane * GSR_SH_ROW4 + j] = make_float4(acc[4 * j], acc[4 * j + 1], acc[4 * j + 2], acc[4 * j + 3]);
+		__builtin_amdgcn_wave_barrier();
+		if (nrows > 0) {
+			float4* dst = reinterpret_cast<float4*>(dL_dsh + (size_t)wave_first * 48);
+#pragma unroll
+			for (int it = 0; it < 12; it++) {
+				const int f = it * 64 + lane;
+				if (f < nrows * 12) dst[f] = s_sh[wave][(f / 12) * GSR_SH_ROW4 + (f % 12)];
+			}
+		}
+	} else if (in_range) {
+		float* out = dL_dsh + (size_t)idx * M * 3;
+		for (int i = 0; i < M * 3; i++) out[i] = (i < 48) ? acc[i] : 0.f;
+	}
+}
+
+void gsr_launch_sh_grad_from_views(int P, int D, int M, int V, const float* means3D, const float* cam_pos, const float* dL_dRGB,
+                                   float* dL_dsh, hipStream_t s)
+{
+	const int via_lds = (M == 16 && ((uintptr_t)dL_dsh & 15u) == 0) ? 1 : 0;
+	hipLaunchKernelGGL(gsr_sh_grad_from_views_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, D, M, V, means3D, cam_pos, dL_dRGB,
+	                   dL_dsh, via_lds);
 }

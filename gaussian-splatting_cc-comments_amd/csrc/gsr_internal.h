@@ -136,3 +136,5 @@ struct GsrGaussianBackwardArgs {
 	float* dL_drot;
 };
 void gsr_launch_gaussian_backward(const GsrGaussianBackwardArgs& a, hipStream_t s);
+void gsr_launch_sh_grad_from_views(int P, int D, int M, int V, const float* means3D, const float* cam_pos, const float* dL_dRGB,
+                                   float* dL_dsh, hipStream_t s);

@@ -17,6 +17,10 @@ import torch
 # tests set this to keep the internal dL_dconic tensor of the last backward call in `debug_last`
 KEEP_DEBUG = False
 debug_last = {}
+# View-parallel mode (view_parallel.skip_sh_gradient): the backward does not produce dL_dsh (returned
+# as None) and the clamp-masked dL/dRGB of the view is left in `view_parallel_last["dL_dRGB"]`
+SKIP_SH_GRAD = False
+view_parallel_last = {}
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(os.path.dirname(_HERE), "libgsr_hip.so")
@@ -85,6 +89,8 @@ def lib():
     L.gsr_backward.argtypes = [_i, _i, _i, _i64, _i, _i] + [_vp] * 5 + [_f] + [_vp] * 5 + [_f, _f] + [_vp] * 16 + [_i]
     L.gsr_mark_visible.restype = _i
     L.gsr_mark_visible.argtypes = [_i, _vp, _vp, _vp, _vp, _vp]
+    L.gsr_sh_grad_from_views.restype = _i
+    L.gsr_sh_grad_from_views.argtypes = [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]
     L.gsr_profile_begin.restype = _i
     L.gsr_profile_end.restype = _i
     L.gsr_profile_end.argtypes = [ctypes.POINTER(KernelTime), _i]
@@ -181,7 +187,8 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
         dL_dconic = alloc((P, 2, 2), **f32)
         dL_dopacity = alloc((P, 1), **f32)
         dL_dcov3D = alloc((P, 6), **f32)
-        dL_dsh = alloc((P, M, 3), **f32)
+        skip_sh = bool(SKIP_SH_GRAD) and M > 0
+        dL_dsh = None if skip_sh else alloc((P, M, 3), **f32)
         dL_dscales = alloc((P, 3), **f32)
         dL_drotations = alloc((P, 4), **f32)
         if P != 0:
@@ -201,7 +208,26 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
             scratch.record_stream(torch.cuda.current_stream(dev))
     if KEEP_DEBUG:
         debug_last["dL_dconic"] = dL_dconic
+    if skip_sh:
+        view_parallel_last["dL_dRGB"] = dL_dcolors
     return dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations
+
+
+def sh_grad_from_views(means3D, cam_pos, dL_dRGB, degree, M):
+    """dL_dsh (P,M,3) summed over V views from their clamp-masked dL/dRGB (V,P,3) and camera
+    positions (V,3): include/gsr.h gsr_sh_grad_from_views."""
+    if not means3D.is_cuda:
+        raise RuntimeError("means3D must be a HIP (cuda) tensor; the HIP rasterizer has no CPU path")
+    L = lib()
+    dev = means3D.device
+    P, V = int(means3D.size(0)), int(dL_dRGB.size(0))
+    assert dL_dRGB.shape == (V, P, 3) and cam_pos.shape == (V, 3)
+    means3D, cam_pos, dL_dRGB = (_dev_f32(t, dev, n) for t, n in ((means3D, "means3D"), (cam_pos, "cam_pos"), (dL_dRGB, "dL_dRGB")))
+    with torch.cuda.device(dev):
+        out = torch.empty((P, M, 3), dtype=torch.float32, device=dev)
+        _check(L.gsr_sh_grad_from_views(P, int(degree), int(M), V, _ptr(means3D), _ptr(cam_pos), _ptr(dL_dRGB), _ptr(out),
+                                        _stream(dev)))
+    return out
 
 
 def mark_visible(means3D, viewmatrix, projmatrix):

@@ -119,7 +119,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         grads = (
             grad_means3D,
             grad_means2D,
-            grad_sh if sh.numel() != 0 else None,
+            grad_sh if (sh.numel() != 0 and grad_sh is not None) else None,
             grad_colors_precomp if colors_precomp.numel() != 0 else None,
             grad_opacities,
             grad_scales if scales.numel() != 0 else None,

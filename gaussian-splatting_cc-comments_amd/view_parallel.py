@@ -59,6 +59,48 @@ class GradientBucket:
         return work
 
 
+class skip_sh_gradient:
+    """Context manager for the backward of ONE view in view-parallel mode: the rasterizer does not
+    produce dL_dsh (48 of the 59 gradient floats per Gaussian); instead the clamp-masked dL/dRGB of
+    the view (3 floats per Gaussian) is collected in `.dL_dRGB` for exchange_sh_gradient()."""
+
+    def __enter__(self):
+        from diff_gaussian_rasterization import _C
+        self._C = _C
+        self._prev = _C.SKIP_SH_GRAD
+        _C.SKIP_SH_GRAD = True
+        _C.view_parallel_last.pop("dL_dRGB", None)
+        self.dL_dRGB = None
+        return self
+
+    def __exit__(self, *exc):
+        self._C.SKIP_SH_GRAD = self._prev
+        self.dL_dRGB = self._C.view_parallel_last.pop("dL_dRGB", None)
+        return False
+
+
+def exchange_sh_gradient(means3D: torch.Tensor, campos: torch.Tensor, dL_dRGB: torch.Tensor, sh_degree: int,
+                         num_coeffs: int, group: Optional[dist.ProcessGroup] = None) -> torch.Tensor:
+    """SH gradient summed over the views of all ranks, from a 12-bytes-per-Gaussian exchange.
+
+    dL/dsh of one view is basis(view direction) x dL/dRGB per Gaussian (backward.cu:45-96), so ranks
+    all-gather their view's clamp-masked dL/dRGB (P,3) and camera position (3,) and every rank
+    rebuilds  sum_v basis(dir_v) x dL/dRGB_v  locally with one kernel -- (7/8)*12*P bytes received per
+    rank instead of the 2*(7/8)*192*P bytes of an all-reduce of the (P,16,3) gradient.  xGMI is
+    point-to-point, so bytes per link, not launches, set the time.  Returns (P, num_coeffs, 3)."""
+    from diff_gaussian_rasterization import _C
+    world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+    P = means3D.shape[0]
+    if world > 1:
+        rgb_all = torch.empty((world, P, 3), dtype=dL_dRGB.dtype, device=dL_dRGB.device)
+        cam_all = torch.empty((world, 3), dtype=campos.dtype, device=campos.device)
+        dist.all_gather_into_tensor(rgb_all, dL_dRGB.contiguous(), group=group)
+        dist.all_gather_into_tensor(cam_all, campos.contiguous(), group=group)
+    else:
+        rgb_all, cam_all = dL_dRGB.reshape(1, P, 3), campos.reshape(1, 3)
+    return _C.sh_grad_from_views(means3D.detach(), cam_all, rgb_all, sh_degree, num_coeffs)
+
+
 def all_reduce_max_radii(radii: torch.Tensor, group: Optional[dist.ProcessGroup] = None) -> torch.Tensor:
     """Per-Gaussian MAX of the int32 screen radii over the views of one step (what
     train.py:157 `max_radii2D` consumes in view-parallel mode)."""

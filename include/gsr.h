@@ -143,6 +143,9 @@ int gsr_forward_render(
  *   dL_dpix [3][H][W]; outputs: dL_dmean2D [P][3], dL_dconic [P][4] (the reference's (P,2,2)),
  *   dL_dopacity [P], dL_dcolor [P][3], dL_dmean3D [P][3], dL_dcov3D [P][6], dL_dsh [P][M][3]
  *   (may be NULL when M == 0), dL_dscale [P][3], dL_drot [P][4].
+ * View-parallel mode: with shs given and dL_dsh == NULL the SH gradient is not produced and
+ * dL_dcolor receives dL/dRGB with the channels the forward clamped at 0 zeroed -- the 3 floats per
+ * Gaussian that gsr_sh_grad_from_views() needs; every other output is unchanged.
  */
 int gsr_backward(
 	int P, int D, int M, int64_t num_rendered,
@@ -173,6 +176,17 @@ int gsr_backward(
 	float* dL_dscale,
 	float* dL_drot,
 	void* stream, int debug);
+
+/*
+ * View-parallel SH gradient (no reference counterpart; the reference is single-view, single-GPU).
+ * dL/dsh of one view is the outer product basis(dir) x dL/dRGB per Gaussian (backward.cu:45-96), so
+ * the sum over V views is rebuilt from V x 3 floats per Gaussian instead of exchanging 3*M:
+ *   dL_dsh[g][k][c] = sum_v basis_k(normalize(means3D[g] - cam_pos[v])) * dL_dRGB[v][g][c]   (k < (D+1)^2)
+ * dL_dRGB [V][P][3] are the clamp-masked colour gradients of the V views (gsr_backward, view-parallel
+ * mode), cam_pos [V][3]; dL_dsh [P][M][3] is fully written (rows >= (D+1)^2 zero).  1 <= M <= 16.
+ */
+int gsr_sh_grad_from_views(int P, int D, int M, int V, const float* means3D, const float* cam_pos,
+                           const float* dL_dRGB, float* dL_dsh, void* stream);
 
 /* Replaces CudaRasterizer::Rasterizer::markVisible (rasterizer_impl.cu:162-174):
  * present[i] = 1 iff the view-space z of means3D[i] is > 0.2. */

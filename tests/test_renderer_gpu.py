@@ -134,3 +134,45 @@ def test_giant_elongated_splats_are_never_culled_wrongly():
     h = util.hip_forward_backward(scene, cam, 0, dpix)
     check_forward(h, o, cam)
     check_grads(h, o, dpix, ["dL_dmeans3D", "dL_dopacity", "dL_dsh", "dL_dscales", "dL_drotations"])
+
+
+def test_view_parallel_compact_sh_gradient_equals_sum_of_per_view_gradients():
+    """view_parallel.exchange_sh_gradient: rebuilding the summed SH gradient from 3 floats per Gaussian
+    per view gives exactly the fixed-order sum of the per-view dL_dsh the rasterizer itself produces,
+    and leaves every other gradient untouched."""
+    _need_gpu()
+    import view_parallel
+    from diff_gaussian_rasterization import GaussianRasterizer, _C
+    dev = torch.device("cuda:0")
+    for D, M in ((3, 16), (1, 16), (2, 9)):
+        scene = gsr_scene.make_scene(6000, -3.0, sh_degree=3, seed=50 + D, n_coeffs=M)
+        cams = [gsr_scene.ring_camera(200, 120, k, 8) for k in (0, 3, 5)]
+        g = torch.Generator().manual_seed(9)
+        dpix = torch.randn(3, 120, 200, generator=g).to(dev)
+
+        def run(cam, skip):
+            p = {k: getattr(scene, k).to(dev).clone().requires_grad_(True) for k in ("means3D", "shs", "opacities", "scales", "rotations")}
+            m2 = torch.zeros_like(p["means3D"], requires_grad=True)
+            color, _ = GaussianRasterizer(util.hip_settings(scene, cam, D, dev))(means2D=m2, **p)
+            if skip:
+                with view_parallel.skip_sh_gradient() as side:
+                    color.backward(dpix)
+                return p, side.dL_dRGB
+            color.backward(dpix)
+            return p, None
+
+        ref = [run(c, False)[0] for c in cams]
+        skp = [run(c, True) for c in cams]
+        for (p_ref, (p_skip, rgb)) in zip(ref, skp):
+            assert p_skip["shs"].grad is None and rgb is not None and rgb.shape == (6000, 3)
+            for k in ("means3D", "opacities", "scales", "rotations"):
+                assert torch.equal(p_ref[k].grad, p_skip[k].grad), k
+        want = (ref[0]["shs"].grad + ref[1]["shs"].grad) + ref[2]["shs"].grad
+        rgb_all = torch.stack([s[1] for s in skp])
+        cam_all = torch.stack([c.camera_center for c in cams]).to(dev)
+        got = _C.sh_grad_from_views(scene.means3D.to(dev), cam_all, rgb_all, D, M)
+        assert got.shape == (6000, M, 3)
+        assert torch.equal(got, want), float((got - want).abs().max())
+        # single-process form of the exchange (world size 1)
+        one = view_parallel.exchange_sh_gradient(scene.means3D.to(dev), cam_all[0], rgb_all[0], D, M)
+        assert torch.equal(one, ref[0]["shs"].grad)
