@@ -92,10 +92,12 @@ def exchange_sh_gradient(means3D: torch.Tensor, campos: torch.Tensor, dL_dRGB: t
     world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
     P = means3D.shape[0]
     if world > 1:
-        rgb_all = torch.empty((world, P, 3), dtype=dL_dRGB.dtype, device=dL_dRGB.device)
-        cam_all = torch.empty((world, 3), dtype=campos.dtype, device=campos.device)
-        dist.all_gather_into_tensor(rgb_all, dL_dRGB.contiguous(), group=group)
-        dist.all_gather_into_tensor(cam_all, campos.contiguous(), group=group)
+        # outputs in the concatenated layout (world * n along dim 0): accepted by both RCCL and gloo
+        rgb_all = torch.empty((world * P, 3), dtype=dL_dRGB.dtype, device=dL_dRGB.device)
+        cam_all = torch.empty((world * 3,), dtype=campos.dtype, device=campos.device)
+        dist.all_gather_into_tensor(rgb_all, dL_dRGB.reshape(P, 3).contiguous(), group=group)
+        dist.all_gather_into_tensor(cam_all, campos.reshape(3).contiguous(), group=group)
+        rgb_all, cam_all = rgb_all.view(world, P, 3), cam_all.view(world, 3)
     else:
         rgb_all, cam_all = dL_dRGB.reshape(1, P, 3), campos.reshape(1, 3)
     return _C.sh_grad_from_views(means3D.detach(), cam_all, rgb_all, sh_degree, num_coeffs)

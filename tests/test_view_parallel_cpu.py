@@ -84,3 +84,36 @@ def _stats_worker(rank, world, port, P):
 
 def test_densification_stats_match_per_view_updates_gloo_world2():
     mp.spawn(_stats_worker, args=(2, _free_port(), 513), nprocs=2, join=True)
+
+
+def _exchange_worker(rank, world, port, P):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from diff_gaussian_rasterization import _C
+        seen = {}
+
+        def stub(means3D, cam_all, rgb_all, degree, M):  # stands in for the HIP kernel: records what it is handed
+            seen["cam"], seen["rgb"], seen["D"], seen["M"] = cam_all.clone(), rgb_all.clone(), degree, M
+            return rgb_all.sum(0)[:, None, :].expand(-1, M, -1).contiguous()
+        orig = _C.sh_grad_from_views
+        _C.sh_grad_from_views = stub
+        try:
+            means = torch.zeros(P, 3)
+            rgb = torch.full((P, 3), float(rank + 1)) + torch.arange(P)[:, None]
+            cam = torch.tensor([rank, 10.0 * rank, -4.0])
+            out = view_parallel.exchange_sh_gradient(means, cam, rgb, 2, 9)
+        finally:
+            _C.sh_grad_from_views = orig
+        assert seen["rgb"].shape == (world, P, 3) and seen["cam"].shape == (world, 3) and (seen["D"], seen["M"]) == (2, 9)
+        for r in range(world):  # every rank sees every view, in rank order
+            assert torch.equal(seen["rgb"][r], torch.full((P, 3), float(r + 1)) + torch.arange(P)[:, None])
+            assert torch.equal(seen["cam"][r], torch.tensor([r, 10.0 * r, -4.0]))
+        assert out.shape == (P, 9, 3)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sh_gradient_exchange_wiring_gloo_world2():
+    mp.spawn(_exchange_worker, args=(2, _free_port(), 37), nprocs=2, join=True)
