@@ -112,14 +112,14 @@ def main():
     backend = os.environ.get("GSR_BENCH_BACKEND", "nccl")
     if backend != "nccl":
         local_rank = local_rank % max(1, torch.cuda.device_count())
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)  # before any collective: RCCL binds the communicator to the current device
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
-    dev = torch.device("cuda", local_rank)
-    torch.cuda.set_device(dev)
 
     from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer, _C
     _C.lib()  # fail loudly if the HIP library is missing
