@@ -10,6 +10,7 @@ flat bucket; value = views per second over all ranks (weak scaling).  Prints ONE
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -91,6 +92,56 @@ def cpu_baseline(scene, cam, D):
     dt = time.time() - t0
     return dict(value=1.0 / dt, unit="it/s", cores=cores, kind="port",
                 sample="1 full fwd+bwd step of the same workload (C oracle, OpenMP, all host cores)"), o
+
+
+def bench_loss(image, dev, iters=20):
+    """Not part of `value`: the fused L1+SSIM loss fwd+bwd (include/gsr.h gsr_l1_ssim_loss)
+    next to the stock-PyTorch sequence of train.py:126-128 on the same (3,H,W) image."""
+    import fused_loss
+    from diff_gaussian_rasterization import _C
+    g = torch.Generator().manual_seed(5)
+    gt = (image + 0.05 * torch.randn(image.shape, generator=g).to(dev)).clamp(0, 1)
+    img = image.clone().requires_grad_(True)
+
+    def fused():
+        img.grad = None
+        fused_loss.l1_ssim_loss(img, gt, 0.2).backward()
+
+    taps = torch.tensor([math.exp(-(k - 5) ** 2 / (2 * 1.5 ** 2)) for k in range(11)])
+    taps = taps / taps.sum()
+    w = (taps[:, None] @ taps[None, :]).to(dev).expand(3, 1, 11, 11).contiguous()
+    F = torch.nn.functional
+
+    def stock():  # utils/loss_utils.py:16-63 + train.py:126-128
+        img.grad = None
+        x = img[None]
+        y = gt[None]
+        mu1, mu2 = F.conv2d(x, w, padding=5, groups=3), F.conv2d(y, w, padding=5, groups=3)
+        s11 = F.conv2d(x * x, w, padding=5, groups=3) - mu1.pow(2)
+        s22 = F.conv2d(y * y, w, padding=5, groups=3) - mu2.pow(2)
+        s12 = F.conv2d(x * y, w, padding=5, groups=3) - mu1 * mu2
+        ssim = (((2 * mu1 * mu2 + 1e-4) * (2 * s12 + 9e-4)) / ((mu1.pow(2) + mu2.pow(2) + 1e-4) * (s11 + s22 + 9e-4))).mean()
+        (0.8 * torch.abs(img - gt).mean() + 0.2 * (1.0 - ssim)).backward()
+
+    def timeit(fn):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / iters * 1e3
+
+    t_fused, t_stock = timeit(fused), timeit(stock)
+    _C.profile_begin()
+    fused()
+    kt = dict(_C.profile_end())
+    n = image.numel()
+    return dict(fused_ms=round(t_fused, 4), stock_pytorch_ms=round(t_stock, 4),
+                kernels_ms={k: round(v, 4) for k, v in kt.items()},
+                algorithmic_bytes=int(n * 4 * (2 + 3 + 3 + 2 + 1)),  # A: read x,y write 3 maps; B: read 3 maps, x, y, write grad
+                note="fwd+bwd of loss = 0.8*L1 + 0.2*(1-SSIM) on the rendered (3,H,W) image; not included in `value`")
 
 
 def main():
@@ -239,6 +290,8 @@ def main():
                                parallelism=(f"view-parallel x{world}, SH gradient exchange: {args.sh_exchange}"
                                             if world > 1 else "single view")),
                    roofline=roofline, kernels=kern)
+        if world == 1:
+            out["loss_l1_ssim"] = bench_loss(state["color"].detach(), dev)
         if world == 1 and not args.no_cpu_baseline:
             import numpy as np
             cb, o = cpu_baseline(scene, cam, D)

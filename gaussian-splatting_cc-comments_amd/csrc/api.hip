@@ -429,6 +429,24 @@ extern "C" int gsr_backward(int P, int D, int M, int64_t R, int width, int heigh
 	return gsr_stage_done(s, debug, "gaussian_backward");
 }
 
+extern "C" size_t gsr_loss_scratch_bytes(int C, int H, int W)
+{
+	if (C <= 0 || H <= 0 || W <= 0) return 0;
+	size_t a, b;
+	int n;
+	return gsr_loss_scratch_layout(C, H, W, &a, &b, &n);
+}
+
+extern "C" int gsr_l1_ssim_loss(int C, int H, int W, const float* img, const float* gt, float lambda_dssim, float* loss_out,
+                                float* dL_dimg, void* scratch, void* stream)
+{
+	g_err[0] = 0;
+	if (C <= 0 || H <= 0 || W <= 0) return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "gsr_l1_ssim_loss: bad image size");
+	if (!img || !gt || !loss_out || !scratch) return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "gsr_l1_ssim_loss: NULL pointer");
+	gsr_launch_l1_ssim(C, H, W, img, gt, lambda_dssim, loss_out, dL_dimg, scratch, (hipStream_t)stream);
+	return gsr_stage_done((hipStream_t)stream, 0, "l1_ssim_loss");
+}
+
 extern "C" int gsr_sh_grad_from_views(int P, int D, int M, int V, const float* means3D, const float* cam_pos,
                                       const float* dL_dRGB, float* dL_dsh, void* stream)
 {

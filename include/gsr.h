@@ -188,6 +188,17 @@ int gsr_backward(
 int gsr_sh_grad_from_views(int P, int D, int M, int V, const float* means3D, const float* cam_pos,
                            const float* dL_dRGB, float* dL_dsh, void* stream);
 
+/*
+ * Training loss next to the path: replaces train.py:126-128 with
+ * utils/loss_utils.py:16-63 -- loss = (1 - lambda) * mean|img - gt| + lambda * (1 - SSIM(img, gt)),
+ * 11x11 Gaussian window, sigma 1.5, zero padding -- AND its backward: dL_dimg [C][H][W] is dloss/dimg
+ * (pass NULL for loss only), i.e. the dL_dpix that gsr_backward() consumes.  loss_out: 3 device
+ * floats {loss, l1, ssim}.  scratch: gsr_loss_scratch_bytes(C, H, W) bytes, free after the call.
+ */
+size_t gsr_loss_scratch_bytes(int C, int H, int W);
+int gsr_l1_ssim_loss(int C, int H, int W, const float* img, const float* gt, float lambda_dssim, float* loss_out,
+                     float* dL_dimg, void* scratch, void* stream);
+
 /* Replaces CudaRasterizer::Rasterizer::markVisible (rasterizer_impl.cu:162-174):
  * present[i] = 1 iff the view-space z of means3D[i] is > 0.2. */
 int gsr_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,

@@ -230,3 +230,15 @@ def sh_backward(deg, pos, campos, shs, clamped, dL_dcolor):
     lib().gsro_sh_backward(n, deg, M, _p(pos, _f), _p(campos, _f), _p(shs, _f), _p(clamped, _b), _p(dL_dcolor, _f),
                            _p(dmean, _f), _p(dsh, _f))
     return dmean, dsh
+
+
+def l1_ssim(img, gt, lambda_dssim=0.2, want_grad=True):
+    """(1-lambda)*L1 + lambda*(1-SSIM) of train.py:126-127 / utils/loss_utils.py, in double.
+    -> (loss, l1, ssim, dloss/dimg (C,H,W) float32 or None)"""
+    img, gt = _f32(img), _f32(gt)
+    C, H, W = img.shape
+    out = np.zeros(3, np.float64)
+    grad = np.zeros((C, H, W), np.float32) if want_grad else None
+    rc = lib().gsro_l1_ssim(C, H, W, _p(img, _f), _p(gt, _f), ctypes.c_float(lambda_dssim), _p(out, _d), _p(grad, _f))
+    assert rc == 0
+    return float(out[0]), float(out[1]), float(out[2]), grad

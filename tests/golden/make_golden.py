@@ -18,6 +18,7 @@ import torch
 REF = "/root/reference"
 sys.path.insert(0, REF)
 from utils.graphics_utils import getProjectionMatrix, getWorld2View2  # noqa: E402
+from utils.loss_utils import l1_loss, ssim  # noqa: E402
 from utils.sh_utils import eval_sh  # noqa: E402
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -73,7 +74,31 @@ def camera_fixture():
     np.savez_compressed(os.path.join(HERE, "camera_golden.npz"), **out)
 
 
+def loss_fixture():
+    """train.py:126-127: loss = (1 - lambda) * l1_loss + lambda * (1 - ssim); gradient by torch.autograd."""
+    g = torch.Generator().manual_seed(99)
+    out = {}
+    cases = {}
+    a = torch.rand(3, 45, 70, generator=g)
+    cases["noise"] = (a, torch.rand(3, 45, 70, generator=g))
+    yy, xx = torch.meshgrid(torch.linspace(0, 1, 64), torch.linspace(0, 1, 97), indexing="ij")
+    base = torch.stack([0.5 + 0.5 * torch.sin(9 * xx + 3 * yy), xx * yy, (xx - yy).abs()])
+    cases["smooth"] = ((base + 0.05 * torch.randn(3, 64, 97, generator=g)).clamp(0, 1), base)
+    cases["equal"] = (base.clone(), base.clone())
+    for name, (img, gt) in cases.items():
+        x = img.clone().requires_grad_(True)
+        Ll1 = l1_loss(x, gt)
+        s = ssim(x, gt)
+        loss = (1.0 - 0.2) * Ll1 + 0.2 * (1.0 - s)
+        loss.backward()
+        out[f"{name}_img"], out[f"{name}_gt"] = img.numpy(), gt.numpy()
+        out[f"{name}_vals"] = np.array([loss.item(), Ll1.item(), s.item()], np.float64)
+        out[f"{name}_grad"] = x.grad.numpy()
+    np.savez_compressed(os.path.join(HERE, "loss_golden.npz"), **out)
+
+
 if __name__ == "__main__":
     sh_fixture()
     camera_fixture()
+    loss_fixture()
     print("wrote", sorted(f for f in os.listdir(HERE) if f.endswith(".npz")))
