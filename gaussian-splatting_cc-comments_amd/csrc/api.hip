@@ -239,12 +239,13 @@ extern "C" uint32_t gsr_get_higher_msb(uint32_t n)
 static bool aligned16(const void* p) { return ((uintptr_t)p & 15u) == 0; }
 
 // ---- forward, stage 1 --------------------------------------------------------------------------
-extern "C" int gsr_forward_preprocess(int P, int D, int M, int width, int height, const float* means3D,
-                                      const float* shs, const float* colors_precomp, const float* opacities,
-                                      const float* scales, float scale_modifier, const float* rotations,
-                                      const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
-                                      const float* cam_pos, float tan_fovx, float tan_fovy, int prefiltered,
-                                      int* radii, void* geometry, int64_t* num_rendered_host, void* stream, int debug)
+static int gsr_forward_preprocess_impl(int P, int D, int M, int width, int height, const float* means3D,
+                                       const float* shs, const float* shs_rest, int leaf, const float* colors_precomp,
+                                       const float* opacities, const float* scales, float scale_modifier,
+                                       const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
+                                       const float* projmatrix, const float* cam_pos, float tan_fovx, float tan_fovy,
+                                       int prefiltered, int* radii, void* geometry, int64_t* num_rendered_host,
+                                       void* stream, int debug)
 {
 	g_err[0] = 0;
 	hipStream_t s = (hipStream_t)stream;
@@ -264,7 +265,9 @@ extern "C" int gsr_forward_preprocess(int P, int D, int M, int width, int height
 		return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "image too large for 16-bit tile coordinates");
 	if (!aligned16(geometry)) return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "geometry buffer must be 16-byte aligned");
 
-	GsrPreprocessArgs a;
+	if (leaf && (M > 1 && !shs_rest)) return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "leaf mode: features_rest is NULL");
+	GsrPreprocessArgs a = {};
+	a.leaf = leaf; a.shs_rest = shs_rest;
 	a.P = P; a.D = D; a.M = M; a.W = width; a.H = height;
 	a.means3D = means3D; a.shs = shs; a.colors_precomp = colors_precomp; a.opacities = opacities;
 	a.scales = scales; a.scale_modifier = scale_modifier; a.rotations = rotations; a.cov3D_precomp = cov3D_precomp;
@@ -322,6 +325,31 @@ extern "C" int gsr_forward_preprocess(int P, int D, int M, int width, int height
 	return GSR_OK;
 }
 
+extern "C" int gsr_forward_preprocess(int P, int D, int M, int width, int height, const float* means3D,
+                                      const float* shs, const float* colors_precomp, const float* opacities,
+                                      const float* scales, float scale_modifier, const float* rotations,
+                                      const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
+                                      const float* cam_pos, float tan_fovx, float tan_fovy, int prefiltered,
+                                      int* radii, void* geometry, int64_t* num_rendered_host, void* stream, int debug)
+{
+	return gsr_forward_preprocess_impl(P, D, M, width, height, means3D, shs, nullptr, 0, colors_precomp, opacities, scales,
+	                                   scale_modifier, rotations, cov3D_precomp, viewmatrix, projmatrix, cam_pos, tan_fovx,
+	                                   tan_fovy, prefiltered, radii, geometry, num_rendered_host, stream, debug);
+}
+
+extern "C" int gsr_forward_preprocess_leaf(int P, int D, int M, int width, int height, const float* xyz,
+                                           const float* features_dc, const float* features_rest,
+                                           const float* opacity_logits, const float* log_scales, float scale_modifier,
+                                           const float* raw_rotations, const float* viewmatrix, const float* projmatrix,
+                                           const float* cam_pos, float tan_fovx, float tan_fovy, int prefiltered,
+                                           int* radii, void* geometry, int64_t* num_rendered_host, void* stream,
+                                           int debug)
+{
+	return gsr_forward_preprocess_impl(P, D, M, width, height, xyz, features_dc, features_rest, 1, nullptr, opacity_logits,
+	                                   log_scales, scale_modifier, raw_rotations, nullptr, viewmatrix, projmatrix, cam_pos,
+	                                   tan_fovx, tan_fovy, prefiltered, radii, geometry, num_rendered_host, stream, debug);
+}
+
 // ---- forward, stage 2 --------------------------------------------------------------------------
 extern "C" int gsr_forward_render(int P, int64_t R, int width, int height, const float* background,
                                   const int* radii, void* geometry, void* binning, void* image, float* out_color,
@@ -375,24 +403,33 @@ extern "C" int gsr_forward_render(int P, int64_t R, int width, int height, const
 }
 
 // ---- backward ----------------------------------------------------------------------------------
-extern "C" int gsr_backward(int P, int D, int M, int64_t R, int width, int height, const float* background,
-                            const float* means3D, const float* shs, const float* colors_precomp,
-                            const float* scales, float scale_modifier, const float* rotations,
-                            const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
-                            const float* cam_pos, float tan_fovx, float tan_fovy, const int* radii, void* geometry,
-                            void* binning, void* image, void* scratch, const float* dL_dpix, float* dL_dmean2D,
-                            float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D,
-                            float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, void* stream,
-                            int debug)
+static int gsr_backward_impl(int P, int D, int M, int64_t R, int width, int height, const float* background,
+                             const float* means3D, const float* shs, const float* shs_rest, int leaf,
+                             const float* colors_precomp, const float* scales, float scale_modifier,
+                             const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
+                             const float* projmatrix, const float* cam_pos, float tan_fovx, float tan_fovy,
+                             const int* radii, void* geometry, void* binning, void* image, void* scratch,
+                             const float* dL_dpix, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity,
+                             float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dsh_rest,
+                             float* dL_dscale, float* dL_drot, void* stream, int debug)
 {
 	g_err[0] = 0;
 	hipStream_t s = (hipStream_t)stream;
 	if (P < 0 || R < 0 || width <= 0 || height <= 0) return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "bad sizes");
 	if (P == 0) return GSR_OK;
 	if (!background || !means3D || !viewmatrix || !projmatrix || !radii || !geometry || !image || !dL_dpix ||
-	    !dL_dmean2D || !dL_dconic || !dL_dopacity || !dL_dcolor || !dL_dmean3D || !dL_dcov3D || !dL_dscale || !dL_drot ||
-	    (R > 0 && (!binning || !scratch)))
+	    !dL_dmean2D || !dL_dopacity || !dL_dmean3D || !dL_dscale || !dL_drot || (R > 0 && (!binning || !scratch)))
 		return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "gsr_backward: required pointer is NULL");
+	if (!leaf && (!dL_dconic || !dL_dcolor || !dL_dcov3D))
+		return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "gsr_backward: required pointer is NULL");
+	if (leaf) {
+		if (!shs || !scales || !rotations || (M > 1 && !shs_rest))
+			return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "gsr_backward_leaf: a leaf tensor is NULL");
+		if ((dL_dsh == nullptr) != (dL_dsh_rest == nullptr) && M > 1)
+			return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "gsr_backward_leaf: pass both feature gradients or neither");
+		if (!dL_dsh && !dL_dcolor)
+			return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "gsr_backward_leaf: without feature gradients dL_dRGB is required");
+	}
 	if (!aligned16(geometry) || !aligned16(image) || !aligned16(binning) || !aligned16(scratch))
 		return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "state buffers must be 16-byte aligned");
 
@@ -411,7 +448,8 @@ extern "C" int gsr_backward(int P, int D, int M, int64_t R, int width, int heigh
 		if ((rc = gsr_stage_done(s, debug, "render_backward"))) return rc;
 	}
 
-	GsrGaussianBackwardArgs a;
+	GsrGaussianBackwardArgs a = {};
+	a.leaf = leaf; a.shs_rest = shs_rest; a.dL_dsh_rest = dL_dsh_rest;
 	a.P = P; a.D = D; a.M = M; a.W = width; a.H = height;
 	a.means3D = means3D; a.shs = shs; a.colors_precomp = colors_precomp; a.scales = scales;
 	a.scale_modifier = scale_modifier; a.rotations = rotations; a.cov3D_precomp = cov3D_precomp;
@@ -427,6 +465,38 @@ extern "C" int gsr_backward(int P, int D, int M, int64_t R, int width, int heigh
 		gsr_launch_gaussian_backward(a, s);
 	}
 	return gsr_stage_done(s, debug, "gaussian_backward");
+}
+
+extern "C" int gsr_backward(int P, int D, int M, int64_t R, int width, int height, const float* background,
+                            const float* means3D, const float* shs, const float* colors_precomp,
+                            const float* scales, float scale_modifier, const float* rotations,
+                            const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
+                            const float* cam_pos, float tan_fovx, float tan_fovy, const int* radii, void* geometry,
+                            void* binning, void* image, void* scratch, const float* dL_dpix, float* dL_dmean2D,
+                            float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D,
+                            float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, void* stream,
+                            int debug)
+{
+	return gsr_backward_impl(P, D, M, R, width, height, background, means3D, shs, nullptr, 0, colors_precomp, scales,
+	                         scale_modifier, rotations, cov3D_precomp, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy,
+	                         radii, geometry, binning, image, scratch, dL_dpix, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor,
+	                         dL_dmean3D, dL_dcov3D, dL_dsh, nullptr, dL_dscale, dL_drot, stream, debug);
+}
+
+extern "C" int gsr_backward_leaf(int P, int D, int M, int64_t R, int width, int height, const float* background,
+                                 const float* xyz, const float* features_dc, const float* features_rest,
+                                 const float* log_scales, float scale_modifier, const float* raw_rotations,
+                                 const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx,
+                                 float tan_fovy, const int* radii, void* geometry, void* binning, void* image,
+                                 void* scratch, const float* dL_dpix, float* dL_dmean2D, float* dL_dxyz,
+                                 float* dL_dfeatures_dc, float* dL_dfeatures_rest, float* dL_dopacity_logits,
+                                 float* dL_dlog_scales, float* dL_draw_rotations, float* dL_dRGB, void* stream, int debug)
+{
+	return gsr_backward_impl(P, D, M, R, width, height, background, xyz, features_dc, features_rest, 1, nullptr, log_scales,
+	                         scale_modifier, raw_rotations, nullptr, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, radii,
+	                         geometry, binning, image, scratch, dL_dpix, dL_dmean2D, nullptr, dL_dopacity_logits, dL_dRGB,
+	                         dL_dxyz, nullptr, dL_dfeatures_dc, dL_dfeatures_rest, dL_dlog_scales, dL_draw_rotations, stream,
+	                         debug);
 }
 
 extern "C" size_t gsr_loss_scratch_bytes(int C, int H, int W)
@@ -445,6 +515,29 @@ extern "C" int gsr_l1_ssim_loss(int C, int H, int W, const float* img, const flo
 	if (!img || !gt || !loss_out || !scratch) return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "gsr_l1_ssim_loss: NULL pointer");
 	gsr_launch_l1_ssim(C, H, W, img, gt, lambda_dssim, loss_out, dL_dimg, scratch, (hipStream_t)stream);
 	return gsr_stage_done((hipStream_t)stream, 0, "l1_ssim_loss");
+}
+
+extern "C" int gsr_adam_step(int ngroups, const gsr_adam_group* groups, double beta1, double beta2, double eps,
+                             const int* radii, void* stream)
+{
+	g_err[0] = 0;
+	if (ngroups < 0 || ngroups > GSR_ADAM_MAX_GROUPS) return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "gsr_adam_step: 0..%d groups", GSR_ADAM_MAX_GROUPS);
+	if (ngroups == 0) return GSR_OK;
+	if (!groups) return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "gsr_adam_step: groups is NULL");
+	for (int k = 0; k < ngroups; k++) {
+		const gsr_adam_group& g = groups[k];
+		if (g.numel < 0 || g.step < 1 || (g.numel > 0 && (!g.param || !g.grad || !g.exp_avg || !g.exp_avg_sq)))
+			return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "gsr_adam_step: group %d: NULL tensor, negative size or step < 1", k);
+		if (g.numel > ((int64_t)1 << 41)) return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "gsr_adam_step: group %d too large", k);
+		if (radii && (g.row <= 0 || g.numel % g.row != 0))
+			return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "gsr_adam_step: group %d: numel is not a multiple of row", k);
+	}
+	hipStream_t s = (hipStream_t)stream;
+	{
+		GsrProfScope p(s, "adam");
+		gsr_launch_adam(ngroups, groups, beta1, beta2, eps, radii, s);
+	}
+	return gsr_check_hip(hipGetLastError(), "gsr_adam_kernel launch");
 }
 
 extern "C" int gsr_sh_grad_from_views(int P, int D, int M, int V, const float* means3D, const float* cam_pos,

@@ -159,8 +159,9 @@ __device__ __forceinline__ void gsr_add_slot(const GsrGradSlot* __restrict__ slo
 	acc[5] += s1.y; acc[6] += s1.z; acc[7] += s1.w; acc[8] += s2;
 }
 
-#define GSR_SH_ROW4 13  // LDS row stride in float4: 12 used + 1 pad -> conflict-free ds_read/write_b128 per row
-
+// LEAF: inputs are the optimiser's raw leaves and the outputs are gradients w.r.t. them: the backward
+// of exp / sigmoid / normalize / cat (gaussian_model.py:114-135) is applied in the epilogue.
+template <bool LEAF>
 __global__ void __launch_bounds__(256) gsr_gaussian_backward_kernel(GsrGaussianBackwardArgs a, int sh_via_lds, int skip_dsh)
 {
 	__shared__ float4 s_sh[4][64 * GSR_SH_ROW4];
@@ -174,12 +175,8 @@ __global__ void __launch_bounds__(256) gsr_gaussian_backward_kernel(GsrGaussianB
 
 	// ---- stage the wave's SH block (64 x 48 floats, contiguous in HBM) into LDS, coalesced ----
 	if (sh_via_lds && nrows > 0) {
-		const float4* src = reinterpret_cast<const float4*>(a.shs + (size_t)wave_first * 48);
-#pragma unroll
-		for (int it = 0; it < 12; it++) {
-			const int f = it * 64 + lane;
-			if (f < nrows * 12) s_sh[wave][(f / 12) * GSR_SH_ROW4 + (f % 12)] = src[f];
-		}
+		if (LEAF) gsr_sh_rows_load_split(s_sh[wave], a.shs, a.shs_rest, wave_first, nrows, lane);
+		else gsr_sh_rows_load(s_sh[wave], a.shs, wave_first, nrows, lane);
 	}
 
 	// ---- fixed-order sum of this Gaussian's (Gaussian,tile) slots ----
@@ -214,7 +211,9 @@ __global__ void __launch_bounds__(256) gsr_gaussian_backward_kernel(GsrGaussianB
 	float dcolor[3] = {acc[6], acc[7], acc[8]};
 	float dmean3D[3] = {0.f, 0.f, 0.f}, dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 	float dscale[3] = {0.f, 0.f, 0.f}, drot[4] = {0.f, 0.f, 0.f, 0.f};
-	float* dsh_global = (a.dL_dsh && in_range) ? a.dL_dsh + (size_t)idx * M * 3 : nullptr;
+	float* dsh_global = (!LEAF && a.dL_dsh && in_range) ? a.dL_dsh + (size_t)idx * M * 3 : nullptr;
+	float sh_local[48], dsh_local[48];  // LEAF without the LDS path: gathered rows / their gradient
+	float q_raw[4] = {0.f, 0.f, 0.f, 0.f}, q_den = 1.f;
 	float dRGB[3] = {0.f, 0.f, 0.f};  // dL/dcolor with the channels clamped by the forward zeroed
 	float* my_row = reinterpret_cast<float*>(&s_sh[wave][lane * GSR_SH_ROW4]);
 
@@ -228,6 +227,11 @@ __global__ void __launch_bounds__(256) gsr_gaussian_backward_kernel(GsrGaussianB
 		} else {
 			sc[0] = a.scales[3 * idx]; sc[1] = a.scales[3 * idx + 1]; sc[2] = a.scales[3 * idx + 2];
 			q[0] = a.rotations[4 * idx]; q[1] = a.rotations[4 * idx + 1]; q[2] = a.rotations[4 * idx + 2]; q[3] = a.rotations[4 * idx + 3];
+			if (LEAF) {
+				sc[0] = gsr_act_exp(sc[0]); sc[1] = gsr_act_exp(sc[1]); sc[2] = gsr_act_exp(sc[2]);
+				q_raw[0] = q[0]; q_raw[1] = q[1]; q_raw[2] = q[2]; q_raw[3] = q[3];
+				q_den = gsr_act_normalize4(q_raw, q);
+			}
 			gsr_cov3d(sc, a.scale_modifier, q, cov3D);  // recomputed: identical bits to the forward's
 		}
 		const GsrVec3 mean = {a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]};
@@ -299,6 +303,12 @@ __global__ void __launch_bounds__(256) gsr_gaussian_backward_kernel(GsrGaussianB
 					shv[4 * j] = v.x; shv[4 * j + 1] = v.y; shv[4 * j + 2] = v.z; shv[4 * j + 3] = v.w;
 				}
 				gsr_sh_backward(a.D, M, mean, a.cam_pos, shv, a.g.clamped[idx], dcolor, dmean3D, my_row, !skip_dsh, dRGB);
+			} else if (LEAF) {
+				const int used = (a.D + 1) * (a.D + 1);
+				for (int k = 0; k < used; k++)
+					for (int ch = 0; ch < 3; ch++)
+						sh_local[k * 3 + ch] = k == 0 ? a.shs[3 * (size_t)idx + ch] : a.shs_rest[((size_t)idx * (M - 1) + (k - 1)) * 3 + ch];
+				gsr_sh_backward(a.D, used, mean, a.cam_pos, sh_local, a.g.clamped[idx], dcolor, dmean3D, dsh_local, !skip_dsh, dRGB);
 			} else {
 				gsr_sh_backward(a.D, M, mean, a.cam_pos, a.shs + (size_t)idx * M * 3, a.g.clamped[idx], dcolor, dmean3D, dsh_global,
 				                !skip_dsh, dRGB);
@@ -306,6 +316,19 @@ __global__ void __launch_bounds__(256) gsr_gaussian_backward_kernel(GsrGaussianB
 		}
 		if (a.scales)
 			gsr_cov3d_backward(sc, a.scale_modifier, q, dcov, dscale, drot);
+		if (LEAF) {
+			// exp backward: grad * result;  sigmoid backward: grad * ((1 - y) * y)
+			dscale[0] *= sc[0]; dscale[1] *= sc[1]; dscale[2] *= sc[2];
+			const float o = a.g.splat[idx].opacity;
+			dop = dop * ((1.0f - o) * o);
+			// F.normalize backward: y = x / d, d = clamp_min(||x||, 1e-12)
+			float gd = 0.f;
+#pragma unroll
+			for (int k = 0; k < 4; k++) gd += -drot[k] * q_raw[k] / (q_den * q_den);
+			const float r = (q_den > 1e-12f) ? gd / q_den : 0.f;
+#pragma unroll
+			for (int k = 0; k < 4; k++) drot[k] = drot[k] / q_den + q_raw[k] * r;
+		}
 	}
 
 	// ---- dL_dsh: zeros for culled Gaussians; coalesced write-out of the wave's block ----
@@ -319,12 +342,18 @@ __global__ void __launch_bounds__(256) gsr_gaussian_backward_kernel(GsrGaussianB
 		}
 		__builtin_amdgcn_wave_barrier();
 		if (nrows > 0) {
-			float4* dst = reinterpret_cast<float4*>(a.dL_dsh + (size_t)wave_first * 48);
-#pragma unroll
-			for (int it = 0; it < 12; it++) {
-				const int f = it * 64 + lane;
-				if (f < nrows * 12) dst[f] = s_sh[wave][(f / 12) * GSR_SH_ROW4 + (f % 12)];
-			}
+			if (LEAF) gsr_sh_rows_store_split(s_sh[wave], a.dL_dsh, a.dL_dsh_rest, wave_first, nrows, lane);
+			else gsr_sh_rows_store(s_sh[wave], a.dL_dsh, wave_first, nrows, lane);
+		}
+	} else if (LEAF) {
+		if (in_range) {
+			const int used = visible ? (a.D + 1) * (a.D + 1) : 0;
+			for (int k = 0; k < M; k++)
+				for (int ch = 0; ch < 3; ch++) {
+					const float v = k < used ? dsh_local[k * 3 + ch] : 0.f;
+					if (k == 0) a.dL_dsh[3 * (size_t)idx + ch] = v;
+					else a.dL_dsh_rest[((size_t)idx * (M - 1) + (k - 1)) * 3 + ch] = v;
+				}
 		}
 	} else if ((!visible || !a.shs) && dsh_global) {
 		for (int k = 0; k < M * 3; k++) dsh_global[k] = 0.f;
@@ -334,17 +363,19 @@ __global__ void __launch_bounds__(256) gsr_gaussian_backward_kernel(GsrGaussianB
 #pragma unroll
 	for (int k = 0; k < 3; k++) {
 		a.dL_dmean2D[3 * (size_t)idx + k] = dmean2D[k];
-		a.dL_dcolor[3 * (size_t)idx + k] = dcolor[k];
+		if (!LEAF || a.dL_dcolor) a.dL_dcolor[3 * (size_t)idx + k] = dcolor[k];
 		a.dL_dmean3D[3 * (size_t)idx + k] = dmean3D[k];
 		a.dL_dscale[3 * (size_t)idx + k] = dscale[k];
 	}
 #pragma unroll
 	for (int k = 0; k < 4; k++) {
-		a.dL_dconic[4 * (size_t)idx + k] = dconic[k];
+		if (!LEAF || a.dL_dconic) a.dL_dconic[4 * (size_t)idx + k] = dconic[k];
 		a.dL_drot[4 * (size_t)idx + k] = drot[k];
 	}
+	if (!LEAF || a.dL_dcov3D) {
 #pragma unroll
-	for (int k = 0; k < 6; k++) a.dL_dcov3D[6 * (size_t)idx + k] = dcov[k];
+		for (int k = 0; k < 6; k++) a.dL_dcov3D[6 * (size_t)idx + k] = dcov[k];
+	}
 	a.dL_dopacity[idx] = dop;
 }
 
@@ -352,8 +383,13 @@ void gsr_launch_gaussian_backward(const GsrGaussianBackwardArgs& a, hipStream_t 
 {
 	// LDS-transposed SH path: the flagship layout (16 coefficients) with 16-byte aligned tensors
 	const int skip_dsh = (a.shs && !a.dL_dsh) ? 1 : 0;  // view-parallel mode (include/gsr.h)
-	const int sh_via_lds = (a.shs && a.M == 16 && ((uintptr_t)a.shs & 15u) == 0 && (skip_dsh || ((uintptr_t)a.dL_dsh & 15u) == 0)) ? 1 : 0;
-	hipLaunchKernelGGL(gsr_gaussian_backward_kernel, dim3((a.P + 255) / 256), dim3(256), 0, s, a, sh_via_lds, skip_dsh);
+	int sh_via_lds = (a.shs && a.M == 16 && ((uintptr_t)a.shs & 15u) == 0 && (skip_dsh || ((uintptr_t)a.dL_dsh & 15u) == 0)) ? 1 : 0;
+	if (a.leaf) {
+		if (((uintptr_t)a.shs_rest & 15u) != 0 || (!skip_dsh && ((uintptr_t)a.dL_dsh_rest & 15u) != 0)) sh_via_lds = 0;
+		hipLaunchKernelGGL(gsr_gaussian_backward_kernel<true>, dim3((a.P + 255) / 256), dim3(256), 0, s, a, sh_via_lds, skip_dsh);
+	} else {
+		hipLaunchKernelGGL(gsr_gaussian_backward_kernel<false>, dim3((a.P + 255) / 256), dim3(256), 0, s, a, sh_via_lds, skip_dsh);
+	}
 }
 
 // ---- view-parallel SH gradient (no reference counterpart) ------------------------------

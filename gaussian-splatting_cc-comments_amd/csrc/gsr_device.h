@@ -136,6 +136,103 @@ __device__ __forceinline__ void gsr_cov3d(const float* scale, float mod, const f
 	cov3D[3] = Sigma.m[1][1]; cov3D[4] = Sigma.m[1][2]; cov3D[5] = Sigma.m[2][2];
 }
 
+// ---- leaf-parameter activations (scene/gaussian_model.py:114-135 property getters) ----
+// In "leaf" mode the per-Gaussian kernels read the optimiser's raw tensors (_scaling, _rotation,
+// _opacity, _features_dc, _features_rest) and apply these themselves, in the arithmetic PyTorch's
+// elementwise kernels use, so no activated copy ever exists in HBM.
+__device__ __forceinline__ float gsr_act_exp(float x) { return expf(x); }                        // torch.exp
+__device__ __forceinline__ float gsr_act_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }  // torch.sigmoid
+// torch.nn.functional.normalize(q): q / max(||q||_2, 1e-12); returns the denominator.  The pairwise
+// order of the sum of squares is the one PyTorch-ROCm's row reduction produces for 4 elements
+// (measured on MI355X with tools/norm_probe.py: bit-identical on 200 000 random rows).
+__device__ __forceinline__ float gsr_act_normalize4(const float* q, float* out)
+{
+	const float n = sqrtf((q[0] * q[0] + q[1] * q[1]) + (q[2] * q[2] + q[3] * q[3]));
+	const float d = fmaxf(n, 1e-12f);
+	out[0] = q[0] / d; out[1] = q[1] / d; out[2] = q[2] / d; out[3] = q[3] / d;
+	return d;
+}
+
+// ---- wave-cooperative staging of 64 Gaussians x 16 SH coefficients through LDS -----------------------
+// Row layout in LDS: 13 float4 per Gaussian (48 floats used + 1 float4 pad: conflict-free b128 row
+// accesses).  The HBM side is always streamed with coalesced 16-byte accesses.
+#define GSR_SH_ROW4 13
+#define GSR_SH_ROWF (4 * GSR_SH_ROW4)
+
+// packed (P,16,3) tensor -> rows
+__device__ __forceinline__ void gsr_sh_rows_load(float4* __restrict__ rows, const float* __restrict__ shs, int wave_first, int nrows, int lane)
+{
+	const float4* src = reinterpret_cast<const float4*>(shs + (size_t)wave_first * 48);
+#pragma unroll
+	for (int it = 0; it < 12; it++) {
+		const int f = it * 64 + lane;
+		if (f < nrows * 12) rows[(f / 12) * GSR_SH_ROW4 + (f % 12)] = src[f];
+	}
+}
+__device__ __forceinline__ void gsr_sh_rows_store(const float4* __restrict__ rows, float* __restrict__ dst_shs, int wave_first, int nrows, int lane)
+{
+	float4* dst = reinterpret_cast<float4*>(dst_shs + (size_t)wave_first * 48);
+#pragma unroll
+	for (int it = 0; it < 12; it++) {
+		const int f = it * 64 + lane;
+		if (f < nrows * 12) dst[f] = rows[(f / 12) * GSR_SH_ROW4 + (f % 12)];
+	}
+}
+// split leaf tensors _features_dc (P,1,3) + _features_rest (P,15,3) -> the same rows (the torch.cat of
+// gaussian_model.py:124-127 done on the fly)
+__device__ __forceinline__ void gsr_sh_rows_load_split(float4* __restrict__ rows4, const float* __restrict__ dc, const float* __restrict__ rest,
+                                                       int wave_first, int nrows, int lane)
+{
+	float* rows = reinterpret_cast<float*>(rows4);
+	const float* dcw = dc + (size_t)wave_first * 3;
+#pragma unroll
+	for (int i = 0; i < 3; i++) {
+		const int e = lane + 64 * i;
+		if (e < nrows * 3) rows[(e / 3) * GSR_SH_ROWF + e % 3] = dcw[e];
+	}
+	const float* rw = rest + (size_t)wave_first * 45;
+	const int n = nrows * 45;
+#pragma unroll
+	for (int it = 0; it < 12; it++) {
+		const int e0 = (it * 64 + lane) * 4;
+		if (e0 + 3 < n) {
+			const float4 v = *reinterpret_cast<const float4*>(rw + e0);
+			const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+			for (int j = 0; j < 4; j++) { const int e = e0 + j; rows[(e / 45) * GSR_SH_ROWF + 3 + e % 45] = vv[j]; }
+		} else {
+#pragma unroll
+			for (int j = 0; j < 4; j++) { const int e = e0 + j; if (e < n) rows[(e / 45) * GSR_SH_ROWF + 3 + e % 45] = rw[e]; }
+		}
+	}
+}
+__device__ __forceinline__ void gsr_sh_rows_store_split(const float4* __restrict__ rows4, float* __restrict__ dc, float* __restrict__ rest,
+                                                        int wave_first, int nrows, int lane)
+{
+	const float* rows = reinterpret_cast<const float*>(rows4);
+	float* dcw = dc + (size_t)wave_first * 3;
+#pragma unroll
+	for (int i = 0; i < 3; i++) {
+		const int e = lane + 64 * i;
+		if (e < nrows * 3) dcw[e] = rows[(e / 3) * GSR_SH_ROWF + e % 3];
+	}
+	float* rw = rest + (size_t)wave_first * 45;
+	const int n = nrows * 45;
+#pragma unroll
+	for (int it = 0; it < 12; it++) {
+		const int e0 = (it * 64 + lane) * 4;
+		float vv[4];
+#pragma unroll
+		for (int j = 0; j < 4; j++) { const int e = min(e0 + j, 64 * 45 - 1); vv[j] = rows[(e / 45) * GSR_SH_ROWF + 3 + e % 45]; }
+		if (e0 + 3 < n) {
+			*reinterpret_cast<float4*>(rw + e0) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+		} else {
+#pragma unroll
+			for (int j = 0; j < 4; j++) if (e0 + j < n) rw[e0 + j] = vv[j];
+		}
+	}
+}
+
 // forward.cu:84-140 computeCov2D, also recomputed by backward.cu:144-199
 struct GsrCov2D {
 	GsrMat3 T, W, Vrk;

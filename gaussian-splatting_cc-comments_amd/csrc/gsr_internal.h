@@ -80,6 +80,10 @@ struct GsrPreprocessArgs {
 	int prefiltered;
 	int* radii;
 	GsrGeometry g;
+	// leaf mode (gsr_forward_preprocess_leaf): shs = _features_dc, shs_rest = _features_rest,
+	// opacities / scales / rotations are the raw leaves and are activated inside the kernel
+	int leaf;
+	const float* shs_rest;
 };
 
 // preprocess.hip
@@ -134,6 +138,12 @@ struct GsrGaussianBackwardArgs {
 	float* dL_dsh;
 	float* dL_dscale;
 	float* dL_drot;
+	// leaf mode (gsr_backward_leaf): inputs as in GsrPreprocessArgs; dL_dsh = grad of _features_dc,
+	// dL_dsh_rest = grad of _features_rest, dL_dopacity/dL_dscale/dL_drot are gradients w.r.t. the raw
+	// leaves; dL_dconic, dL_dcolor, dL_dcov3D may be NULL (not written)
+	int leaf;
+	const float* shs_rest;
+	float* dL_dsh_rest;
 };
 void gsr_launch_gaussian_backward(const GsrGaussianBackwardArgs& a, hipStream_t s);
 void gsr_launch_sh_grad_from_views(int P, int D, int M, int V, const float* means3D, const float* cam_pos, const float* dL_dRGB,
@@ -143,3 +153,6 @@ void gsr_launch_sh_grad_from_views(int P, int D, int M, int V, const float* mean
 size_t gsr_loss_scratch_layout(int C, int H, int W, size_t* maps_off, size_t* partial_off, int* ntiles);
 void gsr_launch_l1_ssim(int C, int H, int W, const float* img, const float* gt, float lambda, float* loss_out, float* dL_dimg,
                         void* scratch, hipStream_t s);
+
+// optimizer.hip
+int gsr_launch_adam(int ngroups, const gsr_adam_group* groups, double beta1, double beta2, double eps, const int* radii, hipStream_t s);

@@ -33,8 +33,8 @@ __device__ __forceinline__ float gsr_sh_channel(int deg, const float* sh, int ch
 	return result + 0.5f;
 }
 
-#define GSR_SH_ROW4 13  // LDS row stride in float4: 12 used + 1 pad -> conflict-free 16-byte accesses per row
-
+// LEAF: the inputs are the optimiser's raw leaves (gsr_internal.h); activations happen here.
+template <bool LEAF>
 __global__ void __launch_bounds__(GSR_PREPROCESS_BLOCK) gsr_preprocess_kernel(GsrPreprocessArgs a, int sh_via_lds)
 {
 	__shared__ float4 s_sh[GSR_PREPROCESS_BLOCK / 64][64 * GSR_SH_ROW4];
@@ -46,12 +46,8 @@ __global__ void __launch_bounds__(GSR_PREPROCESS_BLOCK) gsr_preprocess_kernel(Gs
 		const int wave_first = blockIdx.x * GSR_PREPROCESS_BLOCK + wave * 64;
 		const int nrows = min(64, a.P - wave_first);
 		if (nrows > 0) {
-			const float4* src = reinterpret_cast<const float4*>(a.shs + (size_t)wave_first * 48);
-#pragma unroll
-			for (int it = 0; it < 12; it++) {
-				const int f = it * 64 + lane;
-				if (f < nrows * 12) s_sh[wave][(f / 12) * GSR_SH_ROW4 + (f % 12)] = src[f];
-			}
+			if (LEAF) gsr_sh_rows_load_split(s_sh[wave], a.shs, a.shs_rest, wave_first, nrows, lane);
+			else gsr_sh_rows_load(s_sh[wave], a.shs, wave_first, nrows, lane);
 		}
 		__builtin_amdgcn_wave_barrier();
 	}
@@ -83,6 +79,10 @@ __global__ void __launch_bounds__(GSR_PREPROCESS_BLOCK) gsr_preprocess_kernel(Gs
 			} else {
 				float sc[3] = {a.scales[3 * idx], a.scales[3 * idx + 1], a.scales[3 * idx + 2]};
 				float q[4] = {a.rotations[4 * idx], a.rotations[4 * idx + 1], a.rotations[4 * idx + 2], a.rotations[4 * idx + 3]};
+				if (LEAF) {
+					sc[0] = gsr_act_exp(sc[0]); sc[1] = gsr_act_exp(sc[1]); sc[2] = gsr_act_exp(sc[2]);
+					gsr_act_normalize4(q, q);
+				}
 				gsr_cov3d(sc, a.scale_modifier, q, cov3D);
 			}
 			GsrCov2D c2;
@@ -111,6 +111,14 @@ __global__ void __launch_bounds__(GSR_PREPROCESS_BLOCK) gsr_preprocess_kernel(Gs
 				dx = dx / len; dy = dy / len; dz = dz / len;
 				const float* sh = sh_via_lds ? reinterpret_cast<const float*>(&s_sh[threadIdx.x >> 6][(threadIdx.x & 63) * GSR_SH_ROW4])
 				                             : a.shs + (size_t)idx * a.M * 3;
+				float sh_local[48];
+				if (LEAF && !sh_via_lds) {  // generic M / unaligned leaves: gather the used rows
+					const int used = (a.D + 1) * (a.D + 1);
+					for (int k = 0; k < used; k++)
+						for (int ch = 0; ch < 3; ch++)
+							sh_local[k * 3 + ch] = k == 0 ? a.shs[3 * (size_t)idx + ch] : a.shs_rest[((size_t)idx * (a.M - 1) + (k - 1)) * 3 + ch];
+					sh = sh_local;
+				}
 #pragma unroll
 				for (int ch = 0; ch < 3; ch++) {
 					float v = gsr_sh_channel(a.D, sh, ch, dx, dy, dz);
@@ -124,7 +132,7 @@ __global__ void __launch_bounds__(GSR_PREPROCESS_BLOCK) gsr_preprocess_kernel(Gs
 			a.g.clamped[idx] = clamp_bits;
 			float4* rec = reinterpret_cast<float4*>(a.g.splat + idx);
 			rec[0] = make_float4(pix, piy, conic_a, conic_b);
-			rec[1] = make_float4(conic_c, a.opacities[idx], rgb[0], rgb[1]);
+			rec[1] = make_float4(conic_c, LEAF ? gsr_act_sigmoid(a.opacities[idx]) : a.opacities[idx], rgb[0], rgb[1]);
 			rec[2] = make_float4(rgb[2], 0.f /* slot_base: filled after the scan */,
 			                     __uint_as_float((uint32_t)minx | ((uint32_t)miny << 16)),
 			                     __uint_as_float((uint32_t)(maxx - minx) | ((uint32_t)(maxy - miny) << 16)));
@@ -154,8 +162,13 @@ void gsr_launch_preprocess(const GsrPreprocessArgs& a, hipStream_t s)
 {
 	const int nb = (a.P + GSR_PREPROCESS_BLOCK - 1) / GSR_PREPROCESS_BLOCK;
 	// LDS-transposed SH path: the flagship layout (16 coefficients), 16-byte aligned tensor
-	const int sh_via_lds = (a.shs && !a.colors_precomp && a.M == 16 && ((uintptr_t)a.shs & 15u) == 0) ? 1 : 0;
-	hipLaunchKernelGGL(gsr_preprocess_kernel, dim3(nb), dim3(GSR_PREPROCESS_BLOCK), 0, s, a, sh_via_lds);
+	int sh_via_lds = (a.shs && !a.colors_precomp && a.M == 16 && ((uintptr_t)a.shs & 15u) == 0) ? 1 : 0;
+	if (a.leaf) {
+		if (((uintptr_t)a.shs_rest & 15u) != 0) sh_via_lds = 0;
+		hipLaunchKernelGGL(gsr_preprocess_kernel<true>, dim3(nb), dim3(GSR_PREPROCESS_BLOCK), 0, s, a, sh_via_lds);
+	} else {
+		hipLaunchKernelGGL(gsr_preprocess_kernel<false>, dim3(nb), dim3(GSR_PREPROCESS_BLOCK), 0, s, a, sh_via_lds);
+	}
 }
 
 // rasterizer_impl.cu:56-69 checkFrustum: only the view-space z test of in_frustum survives

@@ -6,6 +6,10 @@ scale/rotation-in-kernel vs covariance-in-Python (`pipe.compute_cov3D_python`), 
 same dict.  `pc` is anything with the read interface of scene/gaussian_model.py:114-138
 (get_xyz, get_opacity, get_scaling, get_rotation, get_features, get_covariance, active_sh_degree,
 max_sh_degree) -- e.g. gsr_model.GaussianParams or the reference's own GaussianModel.
+
+Extension (not in the reference): `pipe.fused_activations = True` renders straight from the optimiser
+leaves (`pc._xyz, _features_dc, _features_rest, _opacity, _scaling, _rotation`) with the activations and
+their backward done inside the per-Gaussian kernels (fused_params.py) -- same result dict.
 """
 import math
 
@@ -42,6 +46,16 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
         prefiltered=False,
         debug=pipe.debug,
     )
+    if getattr(pipe, "fused_activations", False) and override_color is None and not pipe.compute_cov3D_python \
+            and not pipe.convert_SHs_python:
+        from fused_params import rasterize_leaf_gaussians
+        rendered_image, radii = rasterize_leaf_gaussians(pc._xyz, screenspace_points, pc._features_dc, pc._features_rest,
+                                                         pc._opacity, pc._scaling, pc._rotation, raster_settings)
+        return {"render": rendered_image,
+                "viewspace_points": screenspace_points,
+                "visibility_filter": radii > 0,
+                "radii": radii}
+
     rasterizer = GaussianRasterizer(raster_settings=raster_settings)
 
     means3D = pc.get_xyz

@@ -99,6 +99,7 @@ class GaussianParams:
         return build_covariance_from_scaling_rotation(self.get_scaling, scaling_modifier, self._rotation)
 
 
-def pipeline_params(convert_SHs_python=False, compute_cov3D_python=False, debug=False):
-    """arguments/__init__.py:82-88 PipelineParams defaults."""
-    return SimpleNamespace(convert_SHs_python=convert_SHs_python, compute_cov3D_python=compute_cov3D_python, debug=debug)
+def pipeline_params(convert_SHs_python=False, compute_cov3D_python=False, debug=False, fused_activations=False):
+    """arguments/__init__.py:82-88 PipelineParams defaults (+ this build's `fused_activations` switch)."""
+    return SimpleNamespace(convert_SHs_python=convert_SHs_python, compute_cov3D_python=compute_cov3D_python, debug=debug,
+                           fused_activations=fused_activations)

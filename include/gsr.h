@@ -199,6 +199,56 @@ size_t gsr_loss_scratch_bytes(int C, int H, int W);
 int gsr_l1_ssim_loss(int C, int H, int W, const float* img, const float* gt, float lambda_dssim, float* loss_out,
                      float* dL_dimg, void* scratch, void* stream);
 
+/*
+ * Leaf-parameter mode: the same forward stage 1 and backward, but fed with the
+ * optimiser's raw leaves of scene/gaussian_model.py:243-250 instead of their activated copies, and
+ * returning gradients w.r.t. those leaves.  Replaces, around the rasterizer call, the property getters
+ * of gaussian_model.py:114-135 and their autograd backward:
+ *     scales    = exp(log_scales)                       rotations = F.normalize(raw_rotations)
+ *     opacities = sigmoid(opacity_logits)                shs       = cat(features_dc, features_rest, dim=1)
+ * features_dc [P][1][3], features_rest [P][M-1][3] (NULL when M == 1).  Stage 2 is unchanged
+ * (gsr_forward_render).  Backward outputs, each fully written: dL_dmean2D [P][3] (screen-space, for
+ * the densification statistic), dL_dxyz [P][3], dL_dfeatures_dc [P][1][3], dL_dfeatures_rest
+ * [P][M-1][3], dL_dopacity_logits [P], dL_dlog_scales [P][3], dL_draw_rotations [P][4].
+ * dL_dRGB [P][3] is optional; view-parallel mode as in gsr_backward: pass both feature gradients as
+ * NULL and dL_dRGB non-NULL.
+ */
+int gsr_forward_preprocess_leaf(
+	int P, int D, int M, int width, int height,
+	const float* xyz, const float* features_dc, const float* features_rest,
+	const float* opacity_logits, const float* log_scales, float scale_modifier, const float* raw_rotations,
+	const float* viewmatrix, const float* projmatrix, const float* cam_pos,
+	float tan_fovx, float tan_fovy, int prefiltered,
+	int* radii, void* geometry, int64_t* num_rendered_host, void* stream, int debug);
+int gsr_backward_leaf(
+	int P, int D, int M, int64_t num_rendered, int width, int height, const float* background,
+	const float* xyz, const float* features_dc, const float* features_rest,
+	const float* log_scales, float scale_modifier, const float* raw_rotations,
+	const float* viewmatrix, const float* projmatrix, const float* cam_pos,
+	float tan_fovx, float tan_fovy, const int* radii,
+	void* geometry, void* binning, void* image, void* scratch, const float* dL_dpix,
+	float* dL_dmean2D, float* dL_dxyz, float* dL_dfeatures_dc, float* dL_dfeatures_rest,
+	float* dL_dopacity_logits, float* dL_dlog_scales, float* dL_draw_rotations, float* dL_dRGB,
+	void* stream, int debug);
+
+/*
+ * One-launch Adam over up to GSR_ADAM_MAX_GROUPS parameter tensors: replaces
+ * torch.optim.Adam.step() as the reference configures it (gaussian_model.py:243-252: betas
+ * (0.9, 0.999), eps 1e-15, no weight decay, no amsgrad), same arithmetic per element:
+ *     exp_avg += (1-b1)*(grad-exp_avg); exp_avg_sq = exp_avg_sq*b2 + (1-b2)*grad^2;
+ *     param  -= lr/(1-b1^step) * exp_avg / (sqrt(exp_avg_sq)/sqrt(1-b2^step) + eps)
+ * `step` is the group's 1-based step count of THIS update.  radii: NULL (reference semantics: every
+ * element is updated) or [P] int -- then rows (numel/row Gaussians of `row` floats) whose radii <= 0
+ * are left untouched ("visible-only" Adam; changes the optimisation, opt-in).
+ */
+#define GSR_ADAM_MAX_GROUPS 8
+typedef struct {
+	float* param; const float* grad; float* exp_avg; float* exp_avg_sq;
+	int64_t numel; int64_t step; double lr; int32_t row;
+} gsr_adam_group;
+int gsr_adam_step(int ngroups, const gsr_adam_group* groups, double beta1, double beta2, double eps,
+                  const int* radii, void* stream);
+
 /* Replaces CudaRasterizer::Rasterizer::markVisible (rasterizer_impl.cu:162-174):
  * present[i] = 1 iff the view-space z of means3D[i] is > 0.2. */
 int gsr_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,
