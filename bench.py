@@ -144,6 +144,72 @@ def bench_loss(image, dev, iters=20):
                 note="fwd+bwd of loss = 0.8*L1 + 0.2*(1-SSIM) on the rendered (3,H,W) image; not included in `value`")
 
 
+def bench_train_step(scene, settings, D, dev, iters=10):
+    """Whole training iteration (render -> L1+SSIM loss -> backward -> Adam step, train.py:93-131,179-181) three
+    ways on the benchmark scene; an extra next to the headline metric, not part of `value`:
+      stock_around : PyTorch activations, stock-PyTorch loss and torch.optim.Adam around the HIP rasterizer
+                     (= the reference's loop with only diff_gaussian_rasterization swapped)
+      fused_loss   : as above with the fused L1+SSIM loss (8f-2)
+      all_fused    : leaf-parameter rasterizer + fused loss + one-launch Adam (8f-3)"""
+    import torch.nn.functional as F
+    import fused_loss
+    import gsr_model
+    from diff_gaussian_rasterization import GaussianRasterizer
+    from fused_params import FusedAdam, rasterize_leaf_gaussians
+    lrs = dict(xyz=1.6e-4, f_dc=2.5e-3, f_rest=2.5e-3 / 20, opacity=0.05, scaling=5e-3, rotation=1e-3)
+    gt = torch.rand(3, settings.image_height, settings.image_width, device=dev)
+    rast = GaussianRasterizer(settings)
+    g1 = torch.exp(-(torch.arange(11, dtype=torch.float32) - 5) ** 2 / (2 * 1.5 ** 2))
+    g1 = g1 / g1.sum()
+    window = (g1[:, None] @ g1[None, :]).expand(3, 1, 11, 11).contiguous().to(dev)
+
+    def stock_loss(image):  # utils/loss_utils.py:16-63 + train.py:126-127
+        x, y = image[None], gt[None]
+        mu1, mu2 = F.conv2d(x, window, padding=5, groups=3), F.conv2d(y, window, padding=5, groups=3)
+        mu1_sq, mu2_sq, mu1_mu2 = mu1.pow(2), mu2.pow(2), mu1 * mu2
+        s1 = F.conv2d(x * x, window, padding=5, groups=3) - mu1_sq
+        s2 = F.conv2d(y * y, window, padding=5, groups=3) - mu2_sq
+        s12 = F.conv2d(x * y, window, padding=5, groups=3) - mu1_mu2
+        ssim = (((2 * mu1_mu2 + 0.01 ** 2) * (2 * s12 + 0.03 ** 2)) / ((mu1_sq + mu2_sq + 0.01 ** 2) * (s1 + s2 + 0.03 ** 2))).mean()
+        return 0.8 * torch.abs(image - gt).mean() + 0.2 * (1.0 - ssim)
+
+    def make(opt_cls):
+        pc = gsr_model.GaussianParams.from_activated(scene.means3D, scene.shs, scene.scales, scene.rotations, scene.opacities,
+                                                     device=dev, active_sh_degree=D)
+        names = ("xyz", "f_dc", "f_rest", "scaling", "rotation", "opacity")
+        groups = [{"params": [torch.nn.Parameter(p.detach())], "lr": lrs[n], "name": n} for n, p in zip(names, pc.parameters())]
+        pc._xyz, pc._features_dc, pc._features_rest, pc._scaling, pc._rotation, pc._opacity = (g["params"][0] for g in groups)
+        return pc, opt_cls(groups, lr=0.0, eps=1e-15)
+
+    def run(mode):
+        pc, opt = make(FusedAdam if mode == "all_fused" else torch.optim.Adam)
+
+        def it():
+            m2 = torch.zeros_like(pc._xyz, requires_grad=True)
+            if mode == "all_fused":
+                image, radii = rasterize_leaf_gaussians(pc._xyz, m2, pc._features_dc, pc._features_rest, pc._opacity, pc._scaling,
+                                                        pc._rotation, settings)
+            else:
+                image, radii = rast(means3D=pc.get_xyz, means2D=m2, shs=pc.get_features, opacities=pc.get_opacity,
+                                    scales=pc.get_scaling, rotations=pc.get_rotation)
+            loss = stock_loss(image) if mode == "stock_around" else fused_loss.l1_ssim_loss(image, gt, 0.2)
+            loss.backward()
+            opt.step()
+            opt.zero_grad(set_to_none=True)
+        for _ in range(3):
+            it()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            it()
+        torch.cuda.synchronize()
+        return round((time.perf_counter() - t0) / iters * 1e3, 4)
+
+    res = {m: run(m) for m in ("stock_around", "fused_loss", "all_fused")}
+    return dict(ms_per_iteration=res, note="render + 0.8*L1+0.2*(1-SSIM) + backward + Adam(6 groups, eps 1e-15) + zero_grad; "
+                                          "parameters move, so V and R drift slightly from the headline workload")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -151,6 +217,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="C3", choices=list(gsr_scene.CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-train-step", action="store_true", help="skip the whole-training-iteration extra (8f rows)")
     ap.add_argument("--sh-exchange", default="compact", choices=["compact", "allreduce"],
                     help="N > 1: 'compact' all-gathers 3 floats/Gaussian/view and rebuilds the summed SH gradient "
                          "locally (view_parallel.exchange_sh_gradient); 'allreduce' sums all 59 floats/Gaussian")
@@ -292,6 +359,10 @@ def main():
                    roofline=roofline, kernels=kern)
         if world == 1:
             out["loss_l1_ssim"] = bench_loss(state["color"].detach(), dev)
+            if not args.no_train_step:
+                for p in params.values():
+                    p.grad = None
+                out["train_iteration"] = bench_train_step(scene, settings, D, dev)
         if world == 1 and not args.no_cpu_baseline:
             import numpy as np
             cb, o = cpu_baseline(scene, cam, D)
