@@ -98,6 +98,20 @@ class GaussianParams:
     def get_covariance(self, scaling_modifier=1):
         return build_covariance_from_scaling_rotation(self.get_scaling, scaling_modifier, self._rotation)
 
+    def save_ply(self, path):
+        """scene/gaussian_model.py:277-295"""
+        import gsr_ply
+        gsr_ply.save_gaussians_ply(path, self._xyz, self._features_dc, self._features_rest, self._opacity, self._scaling, self._rotation)
+
+    @classmethod
+    def load_ply(cls, path, max_sh_degree=3, device=None, requires_grad=True):
+        """scene/gaussian_model.py:323-364 (active_sh_degree = max_sh_degree afterwards, :364)"""
+        import gsr_ply
+        lv = gsr_ply.load_gaussians_ply(path, max_sh_degree)
+        mk = lambda a: torch.from_numpy(a).to(device).requires_grad_(requires_grad)
+        return cls(mk(lv["xyz"]), mk(lv["features_dc"]), mk(lv["features_rest"]), mk(lv["scaling"]), mk(lv["rotation"]), mk(lv["opacity"]),
+                   max_sh_degree, max_sh_degree)
+
 
 def pipeline_params(convert_SHs_python=False, compute_cov3D_python=False, debug=False, fused_activations=False):
     """arguments/__init__.py:82-88 PipelineParams defaults (+ this build's `fused_activations` switch)."""
