@@ -517,6 +517,19 @@ extern "C" int gsr_l1_ssim_loss(int C, int H, int W, const float* img, const flo
 	return gsr_stage_done((hipStream_t)stream, 0, "l1_ssim_loss");
 }
 
+extern "C" size_t gsr_knn_scratch_bytes(int P) { return gsr_knn_scratch_size(P); }
+
+extern "C" int gsr_knn_mean_dist2(int P, const float* points, float* mean_dist2, void* scratch, void* stream)
+{
+	g_err[0] = 0;
+	if (P < 0) return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "gsr_knn_mean_dist2: negative point count");
+	if (P == 0) return GSR_OK;
+	if (!points || !mean_dist2 || !scratch) return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "gsr_knn_mean_dist2: required pointer is NULL");
+	if (!aligned16(scratch)) return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "gsr_knn_mean_dist2: scratch must be 16-byte aligned");
+	gsr_launch_knn(P, points, mean_dist2, scratch, (hipStream_t)stream);
+	return gsr_check_hip(hipGetLastError(), "knn kernels");
+}
+
 extern "C" int gsr_adam_step(int ngroups, const gsr_adam_group* groups, double beta1, double beta2, double eps,
                              const int* radii, void* stream)
 {

@@ -156,3 +156,7 @@ void gsr_launch_l1_ssim(int C, int H, int W, const float* img, const float* gt, 
 
 // optimizer.hip
 int gsr_launch_adam(int ngroups, const gsr_adam_group* groups, double beta1, double beta2, double eps, const int* radii, hipStream_t s);
+
+// knn.hip
+size_t gsr_knn_scratch_size(int P);
+void gsr_launch_knn(int P, const float* points, float* mean_dist2, void* scratch, hipStream_t s);

@@ -249,6 +249,17 @@ typedef struct {
 int gsr_adam_step(int ngroups, const gsr_adam_group* groups, double beta1, double beta2, double eps,
                   const int* radii, void* stream);
 
+/*
+ * Scale initialisation from the input cloud: replaces simple_knn._C.distCUDA2
+ * (submodules/simple-knn/spatial.cu:14-25, simple_knn.cu:175-220), used by create_from_pcd
+ * (scene/gaussian_model.py:215).  mean_dist2[i] = (d0 + d1 + d2) / 3 with d0 <= d1 <= d2 the three
+ * smallest squared fp32 distances from points[i] to the OTHER points (coincident points count with 0;
+ * fewer than 4 points leave FLT_MAX terms in the sum -- ~1.1e38 or +inf -- as in the reference).  Exact search.
+ * points [P][3], mean_dist2 [P]; scratch: gsr_knn_scratch_bytes(P) bytes, free after the call.
+ */
+size_t gsr_knn_scratch_bytes(int P);
+int gsr_knn_mean_dist2(int P, const float* points, float* mean_dist2, void* scratch, void* stream);
+
 /* Replaces CudaRasterizer::Rasterizer::markVisible (rasterizer_impl.cu:162-174):
  * present[i] = 1 iff the view-space z of means3D[i] is > 0.2. */
 int gsr_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,

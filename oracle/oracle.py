@@ -242,3 +242,16 @@ def l1_ssim(img, gt, lambda_dssim=0.2, want_grad=True):
     rc = lib().gsro_l1_ssim(C, H, W, _p(img, _f), _p(gt, _f), ctypes.c_float(lambda_dssim), _p(out, _d), _p(grad, _f))
     assert rc == 0
     return float(out[0]), float(out[1]), float(out[2]), grad
+
+
+def knn_mean_dist2(points):
+    """simple_knn distCUDA2: mean squared distance to the 3 nearest other points, (P,3) f32 -> (P,) f32."""
+    pts = _f32(points)
+    P = pts.shape[0]
+    out = np.empty(P, np.float32)
+    L = lib()
+    L.gsro_knn_mean_dist2.restype = ctypes.c_int
+    L.gsro_knn_mean_dist2.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    rc = L.gsro_knn_mean_dist2(P, pts.ctypes.data, out.ctypes.data)
+    assert rc == 0
+    return out
