@@ -1,0 +1,65 @@
+"""GPU: randomised configurations against the oracle, same bars as test_parity_gpu.py.  Each seed draws
+the image size (never a multiple of the tile), field of view, camera pose -- including cameras INSIDE
+the cloud, where Gaussians sit behind the camera, cross the near plane, trip the 1.3*tan(fov) frustum
+clamp of computeCov2D (forward.cu:94-99, gradient masks backward.cu:181-186) and reach screen radii of
+thousands of pixels -- SH degree, scale spread, scale_modifier and background."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+import gsr_scene
+import util
+from test_parity_gpu import check_forward, check_grads
+
+pytestmark = pytest.mark.gpu
+
+
+def _look_at(eye, target):
+    fwd = target - eye
+    fwd = fwd / np.linalg.norm(fwd)
+    up = np.array([0.0, 1.0, 0.0])
+    if abs(fwd @ up) > 0.95:
+        up = np.array([1.0, 0.0, 0.0])
+    right = np.cross(up, fwd)
+    right /= np.linalg.norm(right)
+    up2 = np.cross(fwd, right)
+    R = np.stack([right, up2, fwd], axis=1)   # camera-to-world rotation, as Camera.R in scene/cameras.py
+    T = -R.T @ eye
+    return R, T
+
+
+@pytest.mark.parametrize("seed", list(range(10)))
+def test_random_configuration_matches_oracle(seed):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    r = np.random.default_rng(1000 + seed)
+    W = int(r.integers(40, 230))
+    H = int(r.integers(30, 150))
+    if W % 16 == 0:
+        W += 3
+    if H % 16 == 0:
+        H += 5
+    D = int(r.integers(0, 4))
+    inside = seed % 2 == 1
+    P = int(r.integers(1000, 3000)) if inside else int(r.integers(2000, 8000))
+    mu = float(r.uniform(-4.0, -2.0))
+    scene = gsr_scene.make_scene(P, mu, sh_degree=D, seed=seed + 500)
+    bg = torch.tensor(r.uniform(0, 1, 3), dtype=torch.float32)
+    scene = scene._replace(bg=bg)
+    eye = r.normal(size=3)
+    eye = eye / np.linalg.norm(eye) * (float(r.uniform(0.2, 1.4)) if inside else float(r.uniform(2.5, 6.0)))
+    R, T = _look_at(eye, r.uniform(-0.5, 0.5, 3))
+    cam = gsr_scene.make_camera(W, H, fovx=float(r.uniform(0.4, 1.9)), R=R, T=T)
+    scale_modifier = float(r.choice([1.0, 1.0, 0.6, 1.7]))
+    o = util.oracle_forward(scene, cam, D, scale_modifier=scale_modifier)
+    assert o["num_rendered"] > 0
+    if inside:   # the configuration must really exercise what it is for
+        assert int((o["radii"] == 0).sum()) > 0, "no Gaussian culled behind / near the camera"
+    dpix = util.fragile_free_dpix(o, cam, seed=seed)
+    h = util.hip_forward_backward(scene, cam, D, dpix, scale_modifier=scale_modifier)
+    check_forward(h, o, cam)
+    check_grads(h, o, dpix, ["dL_dmeans3D", "dL_dmeans2D", "dL_dopacity", "dL_dsh", "dL_dscales", "dL_drotations"])
+    print(f"seed {seed}: {W}x{H} D{D} P{P} inside={inside} R={o['num_rendered']} max radius {int(o['radii'].max())} "
+          f"fov {math.degrees(2 * math.atan(cam.tanfovx)):.0f} deg")
