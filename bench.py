@@ -217,6 +217,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="C3", choices=list(gsr_scene.CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the loss and training-iteration extras (profiling runs)")
     ap.add_argument("--no-train-step", action="store_true", help="skip the whole-training-iteration extra (8f rows)")
     ap.add_argument("--sh-exchange", default="compact", choices=["compact", "allreduce"],
                     help="N > 1: 'compact' all-gathers 3 floats/Gaussian/view and rebuilds the summed SH gradient "
@@ -357,7 +358,7 @@ def main():
                                parallelism=(f"view-parallel x{world}, SH gradient exchange: {args.sh_exchange}"
                                             if world > 1 else "single view")),
                    roofline=roofline, kernels=kern)
-        if world == 1:
+        if world == 1 and not args.no_extras:
             out["loss_l1_ssim"] = bench_loss(state["color"].detach(), dev)
             if not args.no_train_step:
                 for p in params.values():

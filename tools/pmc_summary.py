@@ -3,7 +3,8 @@ per kernel, the average of every counter per dispatch and the derived HBM traffi
 Traffic follows MI355X_MICROARCH.md "HBM": FETCH_SIZE and WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE
 reports half of the bytes of a wide (16 B/lane) read stream, so reads = 2 * FETCH_SIZE * 1024;
 WRITE_SIZE is exact for 16-B-per-lane stores.  Narrower accesses are uncalibrated (noted per kernel).
-usage: python tools/pmc_summary.py gpurun_out profiles/r1_pmc_summary.json [workload]"""
+usage: python tools/pmc_summary.py "gpurun_out/pmc_b*" profiles/r1_pmc_summary.json [workload]
+(first argument: glob of the per-pass output directories; csv files are searched below each)"""
 import collections
 import csv
 import glob
@@ -12,7 +13,8 @@ import sys
 
 src, dst = sys.argv[1], sys.argv[2]
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
-for f in glob.glob(f"{src}/pmc_*/*/*_counter_collection.csv"):
+files = [f for d in glob.glob(src) for f in glob.glob(f"{d}/**/*_counter_collection.csv", recursive=True)]
+for f in files:
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"].split("(")[0].replace("void ", "")
         if k.startswith("gsr_"):
