@@ -545,6 +545,9 @@ extern "C" int gsr_adam_step(int ngroups, const gsr_adam_group* groups, double b
 		if (radii && (g.row <= 0 || g.numel % g.row != 0))
 			return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "gsr_adam_step: group %d: numel is not a multiple of row", k);
 	}
+	int64_t total = 0;
+	for (int k = 0; k < ngroups; k++) total += groups[k].numel;
+	if (total == 0) return GSR_OK;  // nothing to launch
 	hipStream_t s = (hipStream_t)stream;
 	{
 		GsrProfScope p(s, "adam");

@@ -89,3 +89,48 @@ def test_product_package_does_not_import_the_oracle():
                 src = open(os.path.join(dp, f)).read()
                 assert "oracle" not in src.replace("the CPU oracle", "").replace("CPU oracle", "") or f in (), \
                     f"{f} mentions the oracle: the product path must not depend on it"
+
+
+def test_8f_entry_points_validate_before_any_device_work():
+    import fused_params
+    L = _lib()
+    L.gsr_last_error.restype = ctypes.c_char_p
+    L.gsr_knn_scratch_bytes.restype = ctypes.c_size_t
+    assert L.gsr_knn_scratch_bytes(0) == 0 and 0 < L.gsr_knn_scratch_bytes(1000) < L.gsr_knn_scratch_bytes(100000)
+    assert L.gsr_knn_mean_dist2(-1, None, None, None, None) == -1
+    assert L.gsr_knn_mean_dist2(10, None, None, None, None) == -1 and b"NULL" in L.gsr_last_error()
+    assert L.gsr_knn_mean_dist2(0, None, None, None, None) == 0
+    L.gsr_adam_step.argtypes = [ctypes.c_int, ctypes.POINTER(fused_params.AdamGroup), ctypes.c_double, ctypes.c_double,
+                                ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p]
+    assert ctypes.sizeof(fused_params.AdamGroup) == 64    # include/gsr.h gsr_adam_group: 4 pointers, 2 int64, double, int32 (+pad)
+    g = (fused_params.AdamGroup * 1)(fused_params.AdamGroup(None, None, None, None, 8, 0, 1e-3, 1))
+    assert L.gsr_adam_step(1, g, 0.9, 0.999, 1e-15, None, None) == -1 and b"step < 1" in L.gsr_last_error()
+    assert L.gsr_adam_step(9, g, 0.9, 0.999, 1e-15, None, None) == -1
+    assert L.gsr_adam_step(0, None, 0.9, 0.999, 1e-15, None, None) == 0
+    g[0].step, g[0].numel = 1, 0     # an empty group is a no-op, no launch
+    assert L.gsr_adam_step(1, g, 0.9, 0.999, 1e-15, None, None) == 0
+    R = ctypes.c_int64(0)
+    f1 = ctypes.c_float(1)
+    rc = L.gsr_forward_preprocess_leaf(5, 0, 1, 16, 16, None, None, None, None, None, f1, None, None, None, None, f1, f1, 0,
+                                       None, None, ctypes.byref(R), None, 0)
+    assert rc == -1 and b"NULL" in L.gsr_last_error()
+
+
+def test_8f_python_surfaces_refuse_cpu_tensors():
+    import fused_loss
+    import fused_params
+    from simple_knn._C import distCUDA2
+    import diff_gaussian_rasterization as dgr
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        distCUDA2(torch.zeros(8, 3))
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        fused_loss.l1_ssim_loss(torch.zeros(3, 8, 8), torch.zeros(3, 8, 8))
+    p = torch.nn.Parameter(torch.zeros(4, 3))
+    p.grad = torch.ones(4, 3)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        fused_params.FusedAdam([{"params": [p], "lr": 1e-3, "name": "xyz"}], lr=0.0, eps=1e-15).step()
+    s = dgr.GaussianRasterizationSettings(16, 16, 1.0, 1.0, torch.zeros(3), 1.0, torch.eye(4), torch.eye(4), 0,
+                                          torch.zeros(3), False, False)
+    m = torch.zeros(4, 3)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        fused_params.rasterize_leaf_gaussians(m, m, torch.zeros(4, 1, 3), torch.zeros(4, 0, 3), torch.zeros(4, 1), m, torch.zeros(4, 4), s)
