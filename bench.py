@@ -274,8 +274,11 @@ def main():
         if compact:
             with view_parallel.skip_sh_gradient() as side:
                 color.backward(dpix)
-            params["shs"].grad = view_parallel.exchange_sh_gradient(params["means3D"], settings.campos, side.dL_dRGB, D, M)
-            bucket.all_reduce()
+            ex = view_parallel.ShExchange(settings.campos, side.dL_dRGB)     # async all-gather: 12 B per Gaussian per view
+            work = bucket.all_reduce(async_op=True)                          # the other 11 floats per Gaussian
+            params["shs"].grad = ex.finish(params["means3D"], D, M)          # rebuild kernel overlaps the all-reduce
+            if work is not None:
+                work.wait()
         else:
             color.backward(dpix)
             if world > 1:  # view-parallel: sum the 59 floats/Gaussian of parameter gradients over ranks

@@ -557,7 +557,7 @@ extern "C" int gsr_adam_step(int ngroups, const gsr_adam_group* groups, double b
 }
 
 extern "C" int gsr_sh_grad_from_views(int P, int D, int M, int V, const float* means3D, const float* cam_pos,
-                                      const float* dL_dRGB, float* dL_dsh, void* stream)
+                                      const float* dL_dRGB, int64_t view_stride, float* dL_dsh, void* stream)
 {
 	g_err[0] = 0;
 	if (P < 0 || V < 0 || D < 0 || D > 3 || M <= 0 || M > 16 || (D + 1) * (D + 1) > M)
@@ -565,7 +565,9 @@ extern "C" int gsr_sh_grad_from_views(int P, int D, int M, int V, const float* m
 	if (P == 0) return GSR_OK;
 	if (!means3D || !dL_dsh || (V > 0 && (!cam_pos || !dL_dRGB)))
 		return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "gsr_sh_grad_from_views: NULL pointer");
-	gsr_launch_sh_grad_from_views(P, D, M, V, means3D, cam_pos, dL_dRGB, dL_dsh, (hipStream_t)stream);
+	if (view_stride == 0) view_stride = (int64_t)P * 3;
+	if (view_stride < (int64_t)P * 3) return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "gsr_sh_grad_from_views: view_stride < 3 * P");
+	gsr_launch_sh_grad_from_views(P, D, M, V, means3D, cam_pos, dL_dRGB, view_stride, dL_dsh, (hipStream_t)stream);
 	return gsr_stage_done((hipStream_t)stream, 0, "sh_grad_from_views");
 }
 

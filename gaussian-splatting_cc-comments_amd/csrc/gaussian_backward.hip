@@ -421,8 +421,8 @@ void gsr_launch_gaussian_backward(const GsrGaussianBackwardArgs& a, hipStream_t 
 // per-view gradients would give.
 __global__ void __launch_bounds__(256) gsr_sh_grad_from_views_kernel(int P, int D, int M, int V, const float* __restrict__ means3D,
                                                                       const float* __restrict__ cam_pos,
-                                                                      const float* __restrict__ dL_dRGB, float* __restrict__ dL_dsh,
-                                                                      int via_lds)
+                                                                      const float* __restrict__ dL_dRGB, long long view_stride,
+                                                                      float* __restrict__ dL_dsh, int via_lds)
 {
 	__shared__ float4 s_sh[4][64 * GSR_SH_ROW4];
 	const int idx = blockIdx.x * 256 + threadIdx.x;
@@ -435,7 +435,7 @@ __global__ void __launch_bounds__(256) gsr_sh_grad_from_views_kernel(int P, int 
 	if (in_range) {
 		const float mx = means3D[3 * idx], my = means3D[3 * idx + 1], mz = means3D[3 * idx + 2];
 		for (int v = 0; v < V; v++) {
-			const float* g = dL_dRGB + ((size_t)v * P + idx) * 3;
+			const float* g = dL_dRGB + (size_t)v * view_stride + (size_t)idx * 3;
 			const float g0 = g[0], g1 = g[1], g2 = g[2];
 			if (g0 == 0.f && g1 == 0.f && g2 == 0.f) continue;  // culled in this view (or no gradient): adds exact zeros
 			const float dx = mx - cam_pos[3 * v], dy = my - cam_pos[3 * v + 1], dz = mz - cam_pos[3 * v + 2];
@@ -473,9 +473,9 @@ __global__ void __launch_bounds__(256) gsr_sh_grad_from_views_kernel(int P, int 
 }
 
 void gsr_launch_sh_grad_from_views(int P, int D, int M, int V, const float* means3D, const float* cam_pos, const float* dL_dRGB,
-                                   float* dL_dsh, hipStream_t s)
+                                   int64_t view_stride, float* dL_dsh, hipStream_t s)
 {
 	const int via_lds = (M == 16 && ((uintptr_t)dL_dsh & 15u) == 0) ? 1 : 0;
 	hipLaunchKernelGGL(gsr_sh_grad_from_views_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, D, M, V, means3D, cam_pos, dL_dRGB,
-	                   dL_dsh, via_lds);
+	                   (long long)view_stride, dL_dsh, via_lds);
 }

@@ -147,7 +147,7 @@ struct GsrGaussianBackwardArgs {
 };
 void gsr_launch_gaussian_backward(const GsrGaussianBackwardArgs& a, hipStream_t s);
 void gsr_launch_sh_grad_from_views(int P, int D, int M, int V, const float* means3D, const float* cam_pos, const float* dL_dRGB,
-                                   float* dL_dsh, hipStream_t s);
+                                   int64_t view_stride, float* dL_dsh, hipStream_t s);
 
 // loss.hip
 size_t gsr_loss_scratch_layout(int C, int H, int W, size_t* maps_off, size_t* partial_off, int* ntiles);

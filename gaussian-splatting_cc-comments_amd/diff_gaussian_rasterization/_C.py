@@ -90,7 +90,7 @@ def lib():
     L.gsr_mark_visible.restype = _i
     L.gsr_mark_visible.argtypes = [_i, _vp, _vp, _vp, _vp, _vp]
     L.gsr_sh_grad_from_views.restype = _i
-    L.gsr_sh_grad_from_views.argtypes = [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]
+    L.gsr_sh_grad_from_views.argtypes = [_i, _i, _i, _i, _vp, _vp, _vp, _i64, _vp, _vp]
     L.gsr_profile_begin.restype = _i
     L.gsr_profile_end.restype = _i
     L.gsr_profile_end.argtypes = [ctypes.POINTER(KernelTime), _i]
@@ -222,11 +222,17 @@ def sh_grad_from_views(means3D, cam_pos, dL_dRGB, degree, M):
     dev = means3D.device
     P, V = int(means3D.size(0)), int(dL_dRGB.size(0))
     assert dL_dRGB.shape == (V, P, 3) and cam_pos.shape == (V, 3)
-    means3D, cam_pos, dL_dRGB = (_dev_f32(t, dev, n) for t, n in ((means3D, "means3D"), (cam_pos, "cam_pos"), (dL_dRGB, "dL_dRGB")))
+    # views may be strided along dim 0 (blocks of an all-gather with a trailer row): consumed in place
+    if P and not (dL_dRGB.stride(2) == 1 and dL_dRGB.stride(1) == 3 and (V <= 1 or dL_dRGB.stride(0) >= 3 * P)):
+        dL_dRGB = dL_dRGB.contiguous()
+    view_stride = int(dL_dRGB.stride(0)) if (P and V > 1) else 0
+    if dL_dRGB.device != dev or dL_dRGB.dtype != torch.float32:
+        raise RuntimeError("dL_dRGB must be a float32 tensor on the device of means3D")
+    means3D, cam_pos = (_dev_f32(t, dev, n) for t, n in ((means3D, "means3D"), (cam_pos, "cam_pos")))
     with torch.cuda.device(dev):
         out = torch.empty((P, M, 3), dtype=torch.float32, device=dev)
-        _check(L.gsr_sh_grad_from_views(P, int(degree), int(M), V, _ptr(means3D), _ptr(cam_pos), _ptr(dL_dRGB), _ptr(out),
-                                        _stream(dev)))
+        _check(L.gsr_sh_grad_from_views(P, int(degree), int(M), V, _ptr(means3D), _ptr(cam_pos), _ptr(dL_dRGB), view_stride,
+                                        _ptr(out), _stream(dev)))
     return out
 
 

@@ -79,6 +79,39 @@ class skip_sh_gradient:
         return False
 
 
+class ShExchange:
+    """In-flight exchange of one step's SH-gradient inputs (see exchange_sh_gradient).  start() issues ONE
+    asynchronous all-gather of a (P+1, 3) block per rank -- the view's clamp-masked dL/dRGB with the camera
+    position as its last row -- so other work (packing and all-reducing the remaining gradients) can be
+    enqueued behind it; finish() waits for it and rebuilds the summed (P, M, 3) gradient with one kernel,
+    which then overlaps the all-reduce running on the collective's own stream."""
+
+    def __init__(self, campos: torch.Tensor, dL_dRGB: torch.Tensor, group: Optional[dist.ProcessGroup] = None):
+        self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+        self.P = P = dL_dRGB.numel() // 3
+        self.work = None
+        if self.world > 1:
+            mine = torch.empty((P + 1, 3), dtype=dL_dRGB.dtype, device=dL_dRGB.device)
+            mine[:P] = dL_dRGB.reshape(P, 3)
+            mine[P] = campos.reshape(3)
+            # output in the concatenated layout (world * n along dim 0): accepted by both RCCL and gloo
+            self.all = torch.empty((self.world * (P + 1), 3), dtype=dL_dRGB.dtype, device=dL_dRGB.device)
+            self.mine = mine  # kept alive until finish()
+            self.work = dist.all_gather_into_tensor(self.all, mine, group=group, async_op=True)
+        else:
+            self.rgb_all, self.cam_all = dL_dRGB.reshape(1, P, 3), campos.reshape(1, 3)
+
+    def finish(self, means3D: torch.Tensor, sh_degree: int, num_coeffs: int) -> torch.Tensor:
+        from diff_gaussian_rasterization import _C
+        if self.work is not None:
+            self.work.wait()
+            blocks = self.all.view(self.world, self.P + 1, 3)
+            self.rgb_all = blocks[:, :self.P, :]          # (world, P, 3): strided view, made contiguous by the binding
+            self.cam_all = blocks[:, self.P, :].contiguous()
+            self.work = None
+        return _C.sh_grad_from_views(means3D.detach(), self.cam_all, self.rgb_all, sh_degree, num_coeffs)
+
+
 def exchange_sh_gradient(means3D: torch.Tensor, campos: torch.Tensor, dL_dRGB: torch.Tensor, sh_degree: int,
                          num_coeffs: int, group: Optional[dist.ProcessGroup] = None) -> torch.Tensor:
     """SH gradient summed over the views of all ranks, from a 12-bytes-per-Gaussian exchange.
@@ -87,20 +120,9 @@ def exchange_sh_gradient(means3D: torch.Tensor, campos: torch.Tensor, dL_dRGB: t
     all-gather their view's clamp-masked dL/dRGB (P,3) and camera position (3,) and every rank
     rebuilds  sum_v basis(dir_v) x dL/dRGB_v  locally with one kernel -- (7/8)*12*P bytes received per
     rank instead of the 2*(7/8)*192*P bytes of an all-reduce of the (P,16,3) gradient.  xGMI is
-    point-to-point, so bytes per link, not launches, set the time.  Returns (P, num_coeffs, 3)."""
-    from diff_gaussian_rasterization import _C
-    world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
-    P = means3D.shape[0]
-    if world > 1:
-        # outputs in the concatenated layout (world * n along dim 0): accepted by both RCCL and gloo
-        rgb_all = torch.empty((world * P, 3), dtype=dL_dRGB.dtype, device=dL_dRGB.device)
-        cam_all = torch.empty((world * 3,), dtype=campos.dtype, device=campos.device)
-        dist.all_gather_into_tensor(rgb_all, dL_dRGB.reshape(P, 3).contiguous(), group=group)
-        dist.all_gather_into_tensor(cam_all, campos.reshape(3).contiguous(), group=group)
-        rgb_all, cam_all = rgb_all.view(world, P, 3), cam_all.view(world, 3)
-    else:
-        rgb_all, cam_all = dL_dRGB.reshape(1, P, 3), campos.reshape(1, 3)
-    return _C.sh_grad_from_views(means3D.detach(), cam_all, rgb_all, sh_degree, num_coeffs)
+    point-to-point, so bytes per link, not launches, set the time.  Returns (P, num_coeffs, 3).
+    (Synchronous form of ShExchange.)"""
+    return ShExchange(campos, dL_dRGB, group).finish(means3D, sh_degree, num_coeffs)
 
 
 def all_reduce_max_radii(radii: torch.Tensor, group: Optional[dist.ProcessGroup] = None) -> torch.Tensor:

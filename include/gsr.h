@@ -183,10 +183,12 @@ int gsr_backward(
  * the sum over V views is rebuilt from V x 3 floats per Gaussian instead of exchanging 3*M:
  *   dL_dsh[g][k][c] = sum_v basis_k(normalize(means3D[g] - cam_pos[v])) * dL_dRGB[v][g][c]   (k < (D+1)^2)
  * dL_dRGB [V][P][3] are the clamp-masked colour gradients of the V views (gsr_backward, view-parallel
- * mode), cam_pos [V][3]; dL_dsh [P][M][3] is fully written (rows >= (D+1)^2 zero).  1 <= M <= 16.
+ * mode), view v starting at dL_dRGB + v * view_stride floats (0 = densely packed, 3 * P; an
+ * all-gather of per-rank blocks that carry a trailer can be consumed in place), cam_pos [V][3];
+ * dL_dsh [P][M][3] is fully written (rows >= (D+1)^2 zero).  1 <= M <= 16.
  */
 int gsr_sh_grad_from_views(int P, int D, int M, int V, const float* means3D, const float* cam_pos,
-                           const float* dL_dRGB, float* dL_dsh, void* stream);
+                           const float* dL_dRGB, int64_t view_stride, float* dL_dsh, void* stream);
 
 /*
  * Training loss next to the path: replaces train.py:126-128 with

@@ -173,6 +173,10 @@ def test_view_parallel_compact_sh_gradient_equals_sum_of_per_view_gradients():
         got = _C.sh_grad_from_views(scene.means3D.to(dev), cam_all, rgb_all, D, M)
         assert got.shape == (6000, M, 3)
         assert torch.equal(got, want), float((got - want).abs().max())
+        # views handed over as strided blocks with a trailer row (the layout ShExchange all-gathers): consumed in place
+        blocks = torch.full((3, 6001, 3), float("nan"), device=dev)
+        blocks[:, :6000] = rgb_all
+        assert torch.equal(_C.sh_grad_from_views(scene.means3D.to(dev), cam_all, blocks[:, :6000, :], D, M), want)
         # single-process form of the exchange (world size 1)
         one = view_parallel.exchange_sh_gradient(scene.means3D.to(dev), cam_all[0], rgb_all[0], D, M)
         assert torch.equal(one, ref[0]["shs"].grad)
