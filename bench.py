@@ -35,6 +35,9 @@ KERNEL_SYMBOL = {"render_backward": "gsr_render_backward_wave_kernel", "render_f
                  "duplicate_keys": "gsr_duplicate_keys_kernel", "tile_ranges": "gsr_tile_ranges_kernel"}
 
 
+DOMINANT_STAGE = "render_backward"   # the kernel with the largest launch time in every configuration measured
+
+
 def pmc_traffic(stage, workload):
     try:
         d = json.load(open(PMC_SUMMARY))
@@ -290,7 +293,10 @@ def main():
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
-    _C.profile_begin()
+    # Timed region: HIP events only around the dominant kernel (every event record drains the queue for
+    # ~5 us; bracketing all nine stages costs ~80 us per step, 4 % of it).  The full per-kernel table
+    # comes from a second, untimed pass below.
+    _C.profile_begin(only=DOMINANT_STAGE)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -298,7 +304,15 @@ def main():
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    ktimes = _C.profile_end(capacity=64 * max(args.steps, 1))
+    dom_times = [ms for name, ms in _C.profile_end(capacity=4 * max(args.steps, 1)) if name == DOMINANT_STAGE]
+    table_steps = max(3, min(args.steps, 10))
+    _C.profile_begin()
+    for _ in range(table_steps):
+        step()
+    torch.cuda.synchronize()
+    ktimes = _C.profile_end(capacity=64 * table_steps)
+    if world > 1:
+        dist.barrier()
     if world > 1:
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -344,6 +358,10 @@ def main():
         dom = max(kern, key=lambda k: kern[k]["ms"]) if kern else None
         roofline = None
         if dom:
+            if dom == DOMINANT_STAGE and dom_times:   # its launches inside the timed region
+                avg = sum(dom_times) / len(dom_times)
+                kern[dom].update(ms=round(avg, 4), launches=len(dom_times), measured_in="timed region",
+                                 GBps=round(allb[dom] / (avg * 1e-3) / 1e9, 1) if allb.get(dom) and avg > 0 else None)
             a = kern[dom]["GBps"] or 0.0
             roofline = dict(kernel=dom, bound="hbm", achieved=a, peak=HBM_PEAK_GBS, unit="GB/s",
                             frac=round(a / HBM_PEAK_GBS, 4), traffic=pmc_traffic(dom, args.config),
@@ -360,7 +378,10 @@ def main():
                                P=P, V=V, R=R, R_staged_fwd=Rp, views_per_step=world,
                                parallelism=(f"view-parallel x{world}, SH gradient exchange: {args.sh_exchange}"
                                             if world > 1 else "single view")),
-                   roofline=roofline, kernels=kern)
+                   roofline=roofline, kernels=kern,
+                   kernels_note=f"per-kernel ms: HIP events on the launch stream; '{DOMINANT_STAGE}' over the timed region, the "
+                                f"others over {table_steps} extra untimed steps (bracketing every stage inside the timed region "
+                                "would add ~80 us of event drains per step)")
         if world == 1 and not args.no_extras:
             out["loss_l1_ssim"] = bench_loss(state["color"].detach(), dev)
             if not args.no_train_step:

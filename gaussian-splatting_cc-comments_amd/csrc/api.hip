@@ -54,11 +54,15 @@ static std::mutex g_prof_mu;
 static bool g_prof_on = false;
 static std::vector<ProfEntry>* g_prof = nullptr;
 static size_t g_prof_used = 0;
+static char g_prof_only[64] = "";   // when non-empty: record this stage only (every hipEventRecord drains the queue ~5 us)
+static bool g_prof_open = false;
 
 void gsr_prof_mark_begin(hipStream_t s, const char* name)
 {
 	std::lock_guard<std::mutex> lk(g_prof_mu);
-	if (!g_prof_on) return;
+	g_prof_open = false;
+	if (!g_prof_on || (g_prof_only[0] && strcmp(g_prof_only, name) != 0)) return;
+	g_prof_open = true;
 	if (g_prof_used == g_prof->size()) {
 		ProfEntry e;
 		e.name = name;
@@ -74,7 +78,8 @@ void gsr_prof_mark_begin(hipStream_t s, const char* name)
 void gsr_prof_mark_end(hipStream_t s)
 {
 	std::lock_guard<std::mutex> lk(g_prof_mu);
-	if (!g_prof_on || g_prof_used == 0) return;
+	if (!g_prof_on || !g_prof_open || g_prof_used == 0) return;
+	g_prof_open = false;
 	(void)hipEventRecord((*g_prof)[g_prof_used - 1].b, s);
 }
 
@@ -84,7 +89,16 @@ extern "C" int gsr_profile_begin(void)
 	if (!g_prof) g_prof = new std::vector<ProfEntry>();
 	g_prof_used = 0;
 	g_prof_on = true;
+	g_prof_only[0] = 0;
 	return GSR_OK;
+}
+
+extern "C" int gsr_profile_begin_only(const char* stage)
+{
+	const int rc = gsr_profile_begin();
+	std::lock_guard<std::mutex> lk(g_prof_mu);
+	if (stage) { strncpy(g_prof_only, stage, sizeof g_prof_only - 1); g_prof_only[sizeof g_prof_only - 1] = 0; }
+	return rc;
 }
 
 extern "C" int gsr_profile_end(gsr_kernel_time* out, int capacity)

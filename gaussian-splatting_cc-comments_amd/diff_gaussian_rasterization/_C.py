@@ -272,8 +272,12 @@ def binning_layout(P, R, W, H):
     return o
 
 
-def profile_begin():
-    lib().gsr_profile_begin()
+def profile_begin(only=None):
+    """Start recording per-stage HIP events; `only` = name of the single stage to record."""
+    if only is None:
+        lib().gsr_profile_begin()
+    else:
+        lib().gsr_profile_begin_only(ctypes.c_char_p(only.encode()))
 
 
 def profile_end(capacity=256):

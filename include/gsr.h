@@ -278,6 +278,9 @@ uint32_t gsr_get_higher_msb(uint32_t n);
  */
 typedef struct { const char* name; float ms; } gsr_kernel_time;
 int gsr_profile_begin(void);
+/* Same, recording only the stage called `stage` ("render_backward", "sort", ...): two event records per
+ * step instead of two per stage, for timed regions (each record costs ~5 us of queue drain on the GPU). */
+int gsr_profile_begin_only(const char* stage);
 int gsr_profile_end(gsr_kernel_time* out, int capacity);
 
 #ifdef __cplusplus
