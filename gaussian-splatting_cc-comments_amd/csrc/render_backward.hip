@@ -132,11 +132,14 @@ __global__ void __launch_bounds__(64 * GSR_WAVES_PER_WG, 1) gsr_render_backward_
 				const v2f power = -0.5f * (ax2 + (B.x * dy) * dy) - bdx * dy;
 				const v2f G = {__expf(power.x), __expf(power.y)};
 				const v2f og = B.y * G;
-				const v2f alpha = {fminf(0.99f, og.x), fminf(0.99f, og.y)};
-				const bool hit0 = contributor < last_contributor[2 * p] && !(power.x > 0.0f) && !(alpha.x < 1.0f / 255.0f);
-				const bool hit1 = contributor < last_contributor[2 * p + 1] && !(power.y > 0.0f) && !(alpha.y < 1.0f / 255.0f);
+				const v2f araw = {fminf(0.99f, og.x), fminf(0.99f, og.y)};
+				const bool hit0 = contributor < last_contributor[2 * p] && !(power.x > 0.0f) && !(araw.x < 1.0f / 255.0f);
+				const bool hit1 = contributor < last_contributor[2 * p + 1] && !(power.y > 0.0f) && !(araw.y < 1.0f / 255.0f);
 				if (__ballot(hit0 || hit1) == 0ull) continue;  // wave-uniform
 				any = true;  // (lanes without a hit add exact zeros below)
+				// A pixel that did not hit runs the same update with alpha = 0, which is the identity on its state
+				// bit for bit (1 - 0 = 1, rcp(1) = 1, T * 1 = T, 0 * c + 1 * acc = acc): no per-state selects
+				const v2f alpha = {hit0 ? araw.x : 0.f, hit1 ? araw.y : 0.f};
 				const v2f oma = 1.f - alpha;
 				const v2f inv1ma = {__builtin_amdgcn_rcpf(oma.x), __builtin_amdgcn_rcpf(oma.y)};  // 1 ulp; IEEE division changed no parity figure
 				const v2f Tn = T[p] * inv1ma;
@@ -149,14 +152,14 @@ __global__ void __launch_bounds__(64 * GSR_WAVES_PER_WG, 1) gsr_render_backward_
 				const v2f n1 = alpha * B.w + oma * ac1[p];
 				const v2f n2 = alpha * Cc.x + oma * ac2[p];
 				dL_dalpha = dL_dalpha * Tn + tfb[p] * inv1ma;
-				// zero the partials of the pixel that did not hit, and leave its state untouched
+				// zero the partials of the pixel that did not hit (dL_dalpha of such a pixel is not zero by itself)
 				const v2f hm = {hit0 ? 1.f : 0.f, hit1 ? 1.f : 0.f};
-				const v2f dch = (alpha * Tn) * hm;      // dchannel_dcolor
+				const v2f dch = alpha * Tn;             // dchannel_dcolor; 0 without a hit
 				const v2f dla = dL_dalpha * hm;
-				T[p] = v2f{hit0 ? Tn.x : T[p].x, hit1 ? Tn.y : T[p].y};
-				ac0[p] = v2f{hit0 ? n0.x : ac0[p].x, hit1 ? n0.y : ac0[p].y};
-				ac1[p] = v2f{hit0 ? n1.x : ac1[p].x, hit1 ? n1.y : ac1[p].y};
-				ac2[p] = v2f{hit0 ? n2.x : ac2[p].x, hit1 ? n2.y : ac2[p].y};
+				T[p] = Tn;
+				ac0[p] = n0;
+				ac1[p] = n1;
+				ac2[p] = n2;
 				acc[6] = __builtin_elementwise_fma(dch, dp0[p], acc[6]);
 				acc[7] = __builtin_elementwise_fma(dch, dp1[p], acc[7]);
 				acc[8] = __builtin_elementwise_fma(dch, dp2[p], acc[8]);
