@@ -210,7 +210,7 @@ __global__ void __launch_bounds__(256) gsr_gaussian_backward_kernel(GsrGaussianB
 				}
 		}
 	}
-	unsigned long long big = __ballot(tiles > GSR_SLOT_COOP);
+	unsigned long long big = __builtin_amdgcn_ballot_w64(tiles > GSR_SLOT_COOP);
 	while (big) {  // wave-uniform
 		const int src = __ffsll((long long)big) - 1;
 		big &= big - 1;

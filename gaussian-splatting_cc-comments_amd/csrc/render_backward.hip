@@ -17,22 +17,27 @@
 #define GSR_BWD_NV 9
 typedef float v2f __attribute__((ext_vector_type(2)));
 
-__global__ void __launch_bounds__(64 * GSR_WAVES_PER_WG, 1) gsr_render_backward_wave_kernel(
+__global__ void __launch_bounds__(64 * GSR_WAVES_PER_WG) __attribute__((amdgpu_waves_per_eu(4, 4))) gsr_render_backward_wave_kernel(
 	int W, int H, int gx, int ntiles, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
 	const GsrSplat* __restrict__ splat, const float* __restrict__ bg, const float* __restrict__ final_Ts,
 	const uint32_t* __restrict__ n_contrib, const uint32_t* __restrict__ tile_max_contrib,
 	const float* __restrict__ dL_dpixels, GsrGradSlot* __restrict__ slots, uint8_t* __restrict__ slot_valid, int cull)
 {
-	__shared__ float4 s_rec[GSR_WAVES_PER_WG][3][64];
+	// per-wave staging of the surviving instances of a batch.  Every per-instance scalar that meets the
+	// float2 pixel pairs is stored TWICE, so a ds_read_b128 delivers it as an aligned register pair ready
+	// for v_pk_*_f32 (the compiler otherwise spends one v_mov per scalar per instance on the duplication)
+	__shared__ float4 s_rec[GSR_WAVES_PER_WG][5][64];
+	__shared__ uint32_t s_bands[GSR_WAVES_PER_WG][64];
 	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 	const int tile = blockIdx.x * GSR_WAVES_PER_WG + wave;
 	if (tile >= ntiles) return;  // wave-uniform; no barriers below
 	float4(*rec)[64] = s_rec[wave];
+	uint32_t* recb = s_bands[wave];
 
 	const int tx = tile % gx, ty = tile / gx;
 	const int px = tx * GSR_TILE_X + (lane & 15);
 	const int py0 = ty * GSR_TILE_Y + (lane >> 4);
-	const float pfx = (float)px;
+	const v2f pfx2 = {(float)px, (float)px};
 	const float x0f = (float)(tx * GSR_TILE_X), y0f = (float)(ty * GSR_TILE_Y);
 
 	const uint2 range = ranges[tile];
@@ -91,15 +96,18 @@ __global__ void __launch_bounds__(64 * GSR_WAVES_PER_WG, 1) gsr_render_backward_
 	for (int base = 0; base < n; base += 64) {
 		const uint32_t bands = (base + lane < n) ? (cull ? gsr_tile_band_mask(ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, x0f, y0f) : 0xFu) : 0u;
 		const bool keep = bands != 0u;
-		const unsigned long long mask = __ballot(keep);
+		const unsigned long long mask = __builtin_amdgcn_ballot_w64(keep);
 		const int cnt = __popcll(mask);
 		if (keep) {
 			const int pos = gsr_mbcnt(mask);
 			const uint32_t rmin = __float_as_uint(rc.z), rwh = __float_as_uint(rc.w);
 			const uint32_t slot = __float_as_uint(rc.y) + ((uint32_t)ty - (rmin >> 16)) * (rwh & 0xffffu) + ((uint32_t)tx - (rmin & 0xffffu));
-			rec[0][pos] = ra;
-			rec[1][pos] = rb;
-			rec[2][pos] = make_float4(rc.x, __int_as_float(n - 1 - (base + lane)), __uint_as_float(slot), __uint_as_float(bands));
+			rec[0][pos] = make_float4(ra.x, ra.x, ra.y, ra.y);  // mean x, y
+			rec[1][pos] = make_float4(ra.z, ra.z, ra.w, ra.w);  // conic a, b
+			rec[2][pos] = make_float4(rb.x, rb.x, rb.y, rb.y);  // conic c, opacity
+			rec[3][pos] = make_float4(rb.z, rb.z, rb.w, rb.w);  // r, g
+			rec[4][pos] = make_float4(rc.x, rc.x, __int_as_float(n - 1 - (base + lane)), __uint_as_float(slot));  // b, position in the full range, slot
+			recb[pos] = bands;
 		}
 		if (base + 64 + lane < n) {
 			const float4* p = reinterpret_cast<const float4*>(splat + id_next);
@@ -109,13 +117,13 @@ __global__ void __launch_bounds__(64 * GSR_WAVES_PER_WG, 1) gsr_render_backward_
 		__builtin_amdgcn_wave_barrier();
 
 		for (int j = 0; j < cnt; j++) {
-			const float4 A = rec[0][j];   // x, y, conic a, conic b
-			const float4 B = rec[1][j];   // conic c, opacity, r, g
-			const float4 Cc = rec[2][j];  // b, position in the full range, slot, band mask
-			const int contributor = __builtin_amdgcn_readfirstlane(__float_as_int(Cc.y));  // backward.cu:511-515; wave-uniform
-			const uint32_t bands = __builtin_amdgcn_readfirstlane(__float_as_uint(Cc.w));  // wave-uniform
-			const float dx = A.x - pfx;
-			const float ax2 = (A.z * dx) * dx, bdx = A.w * dx;  // this file is compiled with -ffp-contract=off
+			const float4 R0 = rec[0][j], R1 = rec[1][j], R2 = rec[2][j], R3 = rec[3][j], R4 = rec[4][j];
+			const int contributor = __builtin_amdgcn_readfirstlane(__float_as_int(R4.z));  // backward.cu:511-515; wave-uniform
+			const uint32_t bands = __builtin_amdgcn_readfirstlane(recb[j]);                 // wave-uniform
+			const v2f X = {R0.x, R0.y}, Y = {R0.z, R0.w}, CA = {R1.x, R1.y}, CB = {R1.z, R1.w}, CC = {R2.x, R2.y}, OP = {R2.z, R2.w};
+			const v2f C0 = {R3.x, R3.y}, C1 = {R3.z, R3.w}, C2 = {R4.x, R4.y};
+			const v2f dx = X - pfx2;
+			const v2f ax2 = (CA * dx) * dx, bdx = CB * dx;  // this file is compiled with -ffp-contract=off
 			// per-lane partial sums over its pixels (one float2 = two pixels, added at the end).  The
 			// geometric terms are kept as raw moments of f = G * dL/dG (sum f dx, f dy, f dx^2, f dx dy,
 			// f dy^2); the conic and the 0.5*W / 0.5*H / -0.5 factors of backward.cu:574-594 are applied
@@ -128,14 +136,14 @@ __global__ void __launch_bounds__(64 * GSR_WAVES_PER_WG, 1) gsr_render_backward_
 			for (int p = 0; p < 2; p++) {
 				if (!(bands & (3u << (2 * p))) || contributor >= pair_last[p]) continue;  // scalar branch: no band of this pair can be reached
 				// power = -0.5f * (a*dx*dx + c*dy*dy) - b*dx*dy in the reference's operation order
-				const v2f dy = A.y - pfy[p];
-				const v2f power = -0.5f * (ax2 + (B.x * dy) * dy) - bdx * dy;
+				const v2f dy = Y - pfy[p];
+				const v2f power = -0.5f * (ax2 + (CC * dy) * dy) - bdx * dy;
 				const v2f G = {__expf(power.x), __expf(power.y)};
-				const v2f og = B.y * G;
+				const v2f og = OP * G;
 				const v2f araw = {fminf(0.99f, og.x), fminf(0.99f, og.y)};
 				const bool hit0 = contributor < last_contributor[2 * p] && !(power.x > 0.0f) && !(araw.x < 1.0f / 255.0f);
 				const bool hit1 = contributor < last_contributor[2 * p + 1] && !(power.y > 0.0f) && !(araw.y < 1.0f / 255.0f);
-				if (__ballot(hit0 || hit1) == 0ull) continue;  // wave-uniform
+				if (__builtin_amdgcn_ballot_w64(hit0 || hit1) == 0ull) continue;  // wave-uniform
 				any = true;  // (lanes without a hit add exact zeros below)
 				// A pixel that did not hit runs the same update with alpha = 0, which is the identity on its state
 				// bit for bit (1 - 0 = 1, rcp(1) = 1, T * 1 = T, 0 * c + 1 * acc = acc): no per-state selects
@@ -145,12 +153,12 @@ __global__ void __launch_bounds__(64 * GSR_WAVES_PER_WG, 1) gsr_render_backward_
 				const v2f Tn = T[p] * inv1ma;
 				// accum_rec and (c - accum_rec) cancel heavily when neighbouring colours are close: reference
 				// operation order, no contraction (backward.cu:553-559)
-				v2f dL_dalpha = ((B.z - ac0[p]) * dp0[p] + (B.w - ac1[p]) * dp1[p]) + (Cc.x - ac2[p]) * dp2[p];
+				v2f dL_dalpha = ((C0 - ac0[p]) * dp0[p] + (C1 - ac1[p]) * dp1[p]) + (C2 - ac2[p]) * dp2[p];
 				// the reference updates accum_rec lazily at the NEXT hit from (last_alpha, last_color);
 				// doing it now uses the same operands and yields the same bits, without keeping them
-				const v2f n0 = alpha * B.z + oma * ac0[p];
-				const v2f n1 = alpha * B.w + oma * ac1[p];
-				const v2f n2 = alpha * Cc.x + oma * ac2[p];
+				const v2f n0 = alpha * C0 + oma * ac0[p];
+				const v2f n1 = alpha * C1 + oma * ac1[p];
+				const v2f n2 = alpha * C2 + oma * ac2[p];
 				dL_dalpha = dL_dalpha * Tn + tfb[p] * inv1ma;
 				// zero the partials of the pixel that did not hit (dL_dalpha of such a pixel is not zero by itself)
 				const v2f hm = {hit0 ? 1.f : 0.f, hit1 ? 1.f : 0.f};
@@ -164,15 +172,15 @@ __global__ void __launch_bounds__(64 * GSR_WAVES_PER_WG, 1) gsr_render_backward_
 				acc[7] = __builtin_elementwise_fma(dch, dp1[p], acc[7]);
 				acc[8] = __builtin_elementwise_fma(dch, dp2[p], acc[8]);
 				acc[5] = __builtin_elementwise_fma(G, dla, acc[5]);  // dL/dopacity
-				const v2f f = (B.y * dla) * G;                        // dL/dG * G
+				const v2f f = (OP * dla) * G;                         // dL/dG * G
 				const v2f fdx = f * dx, fdy = f * dy;
 				acc[0] += fdx;
 				acc[1] += fdy;
-				acc[2] = __builtin_elementwise_fma(fdx, v2f{dx, dx}, acc[2]);
+				acc[2] = __builtin_elementwise_fma(fdx, dx, acc[2]);
 				acc[3] = __builtin_elementwise_fma(fdx, dy, acc[3]);
 				acc[4] = __builtin_elementwise_fma(fdy, dy, acc[4]);
 			}
-			if (__ballot(any)) {  // wave-uniform
+			if (__builtin_amdgcn_ballot_w64(any)) {  // wave-uniform
 				float v[GSR_BWD_NV];
 #pragma unroll
 				for (int i = 0; i < GSR_BWD_NV; i++) v[i] = acc[i].x + acc[i].y;
@@ -181,12 +189,12 @@ __global__ void __launch_bounds__(64 * GSR_WAVES_PER_WG, 1) gsr_render_backward_
 				// v[0] ends in group 0 (lane 0), v[1] in group 4 (lane 32): scalar broadcasts
 				const float sx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, t8), 0));
 				const float sy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, t8), 32));
-				const uint32_t slot = __float_as_uint(Cc.z);
+				const uint32_t slot = __float_as_uint(R4.w);
 				float* out = reinterpret_cast<float*>(slots + slot);
 				if ((lane & 7) == 0) {
 					float r = t8;  // out_index 5 (opacity), 6, 7 (colour) are stored as they are
-					if (out_index == 0) r = -ddelx_dx * (A.z * sx + A.w * sy);       // dL/dmean2D.x
-					else if (out_index == 1) r = -ddely_dy * (B.x * sy + A.w * sx);  // dL/dmean2D.y
+					if (out_index == 0) r = -ddelx_dx * (CA.x * sx + CB.x * sy);       // dL/dmean2D.x
+					else if (out_index == 1) r = -ddely_dy * (CC.x * sy + CB.x * sx);  // dL/dmean2D.y
 					else if (out_index <= 4) r = -0.5f * t8;                         // dL/dconic .x .y .w
 					out[out_index] = r;
 				}

@@ -60,10 +60,10 @@ __global__ void __launch_bounds__(64 * GSR_WAVES_PER_WG) gsr_render_forward_wave
 	uint32_t id_next = (64 + lane < n) ? plist[64 + lane] : 0u;
 
 	for (int base = 0; base < n; base += 64) {
-		if (__ballot(fmaxf(fmaxf(Trun[0], Trun[1]), fmaxf(Trun[2], Trun[3])) > 0.f) == 0ull) break;
+		if (__builtin_amdgcn_ballot_w64(fmaxf(fmaxf(Trun[0], Trun[1]), fmaxf(Trun[2], Trun[3])) > 0.f) == 0ull) break;
 		const uint32_t bands = (base + lane < n) ? (cull ? gsr_tile_band_mask(ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, x0f, y0f) : 0xFu) : 0u;
 		const bool keep = bands != 0u;
-		const unsigned long long mask = __ballot(keep);
+		const unsigned long long mask = __builtin_amdgcn_ballot_w64(keep);
 		const int cnt = __popcll(mask);
 		if (keep) {
 			const int pos = gsr_mbcnt(mask);
@@ -89,7 +89,7 @@ __global__ void __launch_bounds__(64 * GSR_WAVES_PER_WG) gsr_render_forward_wave
 #pragma unroll
 			for (int k = 0; k < GSR_PIX_PER_LANE; k++) {
 				if (!(bands & (1u << k))) continue;  // this 16x4 band cannot be reached: scalar branch
-				if (__ballot(Trun[k] > 0.f) == 0ull) continue;  // all 64 pixels of the band are done
+				if (__builtin_amdgcn_ballot_w64(Trun[k] > 0.f) == 0ull) continue;  // all 64 pixels of the band are done
 				const float dy = A.y - pfy[k];
 				const float power = gsr_pair_power(ax2, bdx, B.x, dy);
 				const float alpha = fminf(0.99f, B.y * __expf(power));
@@ -106,7 +106,7 @@ __global__ void __launch_bounds__(64 * GSR_WAVES_PER_WG) gsr_render_forward_wave
 				Trun[k] = live ? (pass ? test_T : 0.0f) : Trun[k];
 				last[k] = pass ? contributor : last[k];
 			}
-			if (__ballot(fmaxf(fmaxf(Trun[0], Trun[1]), fmaxf(Trun[2], Trun[3])) > 0.f) == 0ull) break;
+			if (__builtin_amdgcn_ballot_w64(fmaxf(fmaxf(Trun[0], Trun[1]), fmaxf(Trun[2], Trun[3])) > 0.f) == 0ull) break;
 		}
 		__builtin_amdgcn_wave_barrier();
 	}

@@ -130,10 +130,10 @@ __global__ void __launch_bounds__(GSR_SORT_THREADS) gsr_radix_scatter_kernel(
 		key[it] = valid ? keys_in[i] : 0u;
 		val[it] = valid ? vals_in[i] : 0u;
 		const uint32_t d = (key[it] >> shift) & mask;
-		unsigned long long peers = __ballot(valid);
+		unsigned long long peers = __builtin_amdgcn_ballot_w64(valid);
 		for (int b = 0; b < nbits; b++) {
 			const bool bit = (d >> b) & 1u;
-			const unsigned long long m = __ballot(bit);
+			const unsigned long long m = __builtin_amdgcn_ballot_w64(bit);
 			peers &= bit ? m : ~m;
 		}
 		// peers = valid lanes of this wave holding digit d in this round; lowest one is the leader
