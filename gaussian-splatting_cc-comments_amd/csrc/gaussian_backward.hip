@@ -52,7 +52,7 @@ __device__ __forceinline__ void gsr_sh_basis(int deg, float x, float y, float z,
 // view-direction term of dL_dmean is produced (view-parallel mode, see gsr_sh_grad_from_views).
 __device__ __forceinline__ void gsr_sh_backward(int deg, int M, GsrVec3 pos, const float* campos, const float* sh,
                                                 uint8_t clamp_bits, const float* dL_dcolor, float* dL_dmean,
-                                                float* dL_dsh, bool write_dsh, float* dL_dRGB_out)
+                                                float* dL_dsh, bool write_dsh, float* dL_dRGB_out, float* basis_out = nullptr)
 {
 	GsrVec3 dir_orig = {pos.x - campos[0], pos.y - campos[1], pos.z - campos[2]};
 	float len = sqrtf(dir_orig.x * dir_orig.x + dir_orig.y * dir_orig.y + dir_orig.z * dir_orig.z);
@@ -61,6 +61,10 @@ __device__ __forceinline__ void gsr_sh_backward(int deg, int M, GsrVec3 pos, con
 	const int used = (deg + 1) * (deg + 1);
 	float basis[16];
 	gsr_sh_basis(deg, x, y, z, basis);
+	if (basis_out) {
+#pragma unroll
+		for (int k = 0; k < 16; k++) basis_out[k] = (k < used) ? basis[k] : 0.f;  // entries >= used are never set by gsr_sh_basis
+	}
 #pragma unroll
 	for (int ch = 0; ch < 3; ch++) {
 #define SH(k) sh[(k) * 3 + ch]
@@ -235,7 +239,6 @@ __global__ void __launch_bounds__(256) gsr_gaussian_backward_kernel(GsrGaussianB
 	float sh_local[48], dsh_local[48];  // LEAF without the LDS path: gathered rows / their gradient
 	float q_raw[4] = {0.f, 0.f, 0.f, 0.f}, q_den = 1.f;
 	float dRGB[3] = {0.f, 0.f, 0.f};  // dL/dcolor with the channels clamped by the forward zeroed
-	float* my_row = reinterpret_cast<float*>(&s_sh[wave][lane * GSR_SH_ROW4]);
 
 	if (visible) {
 		// ---- computeCov2DCUDA, backward.cu:144-277 ----
@@ -322,7 +325,21 @@ __global__ void __launch_bounds__(256) gsr_gaussian_backward_kernel(GsrGaussianB
 					const float4 v = s_sh[wave][lane * GSR_SH_ROW4 + j];
 					shv[4 * j] = v.x; shv[4 * j + 1] = v.y; shv[4 * j + 2] = v.z; shv[4 * j + 3] = v.w;
 				}
-				gsr_sh_backward(a.D, M, mean, a.cam_pos, shv, a.g.clamped[idx], dcolor, dmean3D, my_row, !skip_dsh, dRGB);
+				// dL_dsh = basis x dL/dRGB is written below as 12 float4 (the row is conflict-free for 16-byte
+				// accesses; 48 scalar stores at this row stride hit 4-way bank conflicts)
+				float basis[16];
+				const int used_sh = (a.D + 1) * (a.D + 1);
+				gsr_sh_backward(a.D, M, mean, a.cam_pos, shv, a.g.clamped[idx], dcolor, dmean3D, nullptr, false, dRGB, basis);
+				if (!skip_dsh) {
+#pragma unroll
+					for (int j = 0; j < 12; j++) {
+						float o[4];
+#pragma unroll
+						for (int t = 0; t < 4; t++)  // rows >= (D+1)^2 are +0, not the -0 a product with a negative gradient would give
+							o[t] = ((4 * j + t) / 3 < used_sh) ? basis[(4 * j + t) / 3] * dRGB[(4 * j + t) % 3] : 0.f;
+						s_sh[wave][lane * GSR_SH_ROW4 + j] = make_float4(o[0], o[1], o[2], o[3]);
+					}
+				}
 			} else if (LEAF) {
 				const int used = (a.D + 1) * (a.D + 1);
 				for (int k = 0; k < used; k++)
