@@ -38,13 +38,33 @@ KERNEL_SYMBOL = {"render_backward": "gsr_render_backward_wave_kernel", "render_f
 DOMINANT_STAGE = "render_backward"   # the kernel with the largest launch time in every configuration measured
 
 
+def _pmc_entry(stage, workload):
+    d = json.load(open(PMC_SUMMARY))
+    if d.get("_workload") != workload:
+        raise KeyError(workload)
+    sym = KERNEL_SYMBOL[stage]
+    for k, v in d.items():   # templated kernels appear as name<args>
+        if isinstance(v, dict) and (k == sym or k.startswith(sym + "<")):
+            return v
+    raise KeyError(sym)
+
+
 def pmc_traffic(stage, workload):
     try:
-        d = json.load(open(PMC_SUMMARY))
-        if d.get("_workload") != workload:
-            return None
-        return d[KERNEL_SYMBOL[stage]].get("hbm_traffic_bytes")
+        return _pmc_entry(stage, workload).get("hbm_traffic_bytes")
     except (OSError, KeyError, ValueError):
+        return None
+
+
+def pmc_valu_issue(stage, workload):
+    """Fraction of the SIMDs' VALU issue capacity the kernel used, from the committed PMC summary:
+    SQ_ACTIVE_INST_VALU counts quad-cycles summed over waves, SQ_BUSY_CYCLES counts cycles summed over the 32
+    shader engines, 1024 SIMDs: 4 * ACTIVE / (BUSY / 32 * 1024) = ACTIVE / (8 * BUSY).  (Transcendentals issue
+    beside the main pipe, so a kernel full of v_exp/v_rcp can read slightly above 1.)"""
+    try:
+        e = _pmc_entry(stage, workload)
+        return round(e["SQ_ACTIVE_INST_VALU"] / (8.0 * e["SQ_BUSY_CYCLES"]), 3)
+    except (OSError, KeyError, ValueError, ZeroDivisionError):
         return None
 
 
@@ -365,6 +385,7 @@ def main():
             a = kern[dom]["GBps"] or 0.0
             roofline = dict(kernel=dom, bound="hbm", achieved=a, peak=HBM_PEAK_GBS, unit="GB/s",
                             frac=round(a / HBM_PEAK_GBS, 4), traffic=pmc_traffic(dom, args.config),
+                            valu_issue_frac=pmc_valu_issue(dom, args.config),
                             note="this kernel is VALU-issue-bound (PMC: SQ_ACTIVE_INST_VALU ~ 100 % of its duration), "
                                  "so its HBM fraction is small by construction; see 'kernels' for the streaming stages",
                             avg_launch_ms=kern[dom]["ms"], algorithmic_bytes_per_launch=kern[dom]["algorithmic_bytes"],
