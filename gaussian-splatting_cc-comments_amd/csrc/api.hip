@@ -434,8 +434,10 @@ static int gsr_backward_impl(int P, int D, int M, int64_t R, int width, int heig
 	if (!background || !means3D || !viewmatrix || !projmatrix || !radii || !geometry || !image || !dL_dpix ||
 	    !dL_dmean2D || !dL_dopacity || !dL_dmean3D || !dL_dscale || !dL_drot || (R > 0 && (!binning || !scratch)))
 		return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "gsr_backward: required pointer is NULL");
-	if (!leaf && (!dL_dconic || !dL_dcolor || !dL_dcov3D))
-		return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "gsr_backward: required pointer is NULL");
+	// dL_dconic is an intermediate; dL_dcolor / dL_dcov3D are only results when the colours / covariances were
+	// inputs (or, dL_dcolor, in view-parallel mode): NULL = not written
+	if (!leaf && ((colors_precomp && !dL_dcolor) || (cov3D_precomp && !dL_dcov3D) || (shs && !dL_dsh && !dL_dcolor)))
+		return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "gsr_backward: the gradient of a provided input is NULL");
 	if (leaf) {
 		if (!shs || !scales || !rotations || (M > 1 && !shs_rest))
 			return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "gsr_backward_leaf: a leaf tensor is NULL");

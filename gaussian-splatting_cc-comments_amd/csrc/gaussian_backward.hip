@@ -400,16 +400,16 @@ __global__ void __launch_bounds__(256) gsr_gaussian_backward_kernel(GsrGaussianB
 #pragma unroll
 	for (int k = 0; k < 3; k++) {
 		a.dL_dmean2D[3 * (size_t)idx + k] = dmean2D[k];
-		if (!LEAF || a.dL_dcolor) a.dL_dcolor[3 * (size_t)idx + k] = dcolor[k];
+		if (a.dL_dcolor) a.dL_dcolor[3 * (size_t)idx + k] = dcolor[k];
 		a.dL_dmean3D[3 * (size_t)idx + k] = dmean3D[k];
 		a.dL_dscale[3 * (size_t)idx + k] = dscale[k];
 	}
 #pragma unroll
 	for (int k = 0; k < 4; k++) {
-		if (!LEAF || a.dL_dconic) a.dL_dconic[4 * (size_t)idx + k] = dconic[k];
+		if (a.dL_dconic) a.dL_dconic[4 * (size_t)idx + k] = dconic[k];
 		a.dL_drot[4 * (size_t)idx + k] = drot[k];
 	}
-	if (!LEAF || a.dL_dcov3D) {
+	if (a.dL_dcov3D) {
 #pragma unroll
 		for (int k = 0; k < 6; k++) a.dL_dcov3D[6 * (size_t)idx + k] = dcov[k];
 	}

@@ -17,6 +17,11 @@ import torch
 # tests set this to keep the internal dL_dconic tensor of the last backward call in `debug_last`
 KEEP_DEBUG = False
 debug_last = {}
+# Set by _RasterizeGaussians.backward around its call: outputs that autograd would drop anyway (dL_dcolors when the
+# colours came from SH, dL_dcov3D when the covariances came from scales/rotations, the internal dL_dconic) are not
+# computed and come back as empty tensors.  A direct caller of rasterize_gaussians_backward gets all of them, like
+# the reference's extension returns them.
+ONLY_CONSUMED_GRADS = False
 # View-parallel mode (view_parallel.skip_sh_gradient): the backward does not produce dL_dsh (returned
 # as None) and the clamp-masked dL/dRGB of the view is left in `view_parallel_last["dL_dRGB"]`
 SKIP_SH_GRAD = False
@@ -183,11 +188,13 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
         alloc = torch.zeros if P == 0 else torch.empty
         dL_dmeans3D = alloc((P, 3), **f32)
         dL_dmeans2D = alloc((P, 3), **f32)
-        dL_dcolors = alloc((P, 3), **f32)
-        dL_dconic = alloc((P, 2, 2), **f32)
-        dL_dopacity = alloc((P, 1), **f32)
-        dL_dcov3D = alloc((P, 6), **f32)
         skip_sh = bool(SKIP_SH_GRAD) and M > 0
+        lean = bool(ONLY_CONSUMED_GRADS) and not KEEP_DEBUG
+        none = torch.empty((0,), **f32)
+        dL_dcolors = alloc((P, 3), **f32) if (not lean or colors.numel() != 0 or skip_sh) else none
+        dL_dconic = alloc((P, 2, 2), **f32) if not lean else none
+        dL_dopacity = alloc((P, 1), **f32)
+        dL_dcov3D = alloc((P, 6), **f32) if (not lean or cov3D_precomp.numel() != 0) else none
         dL_dsh = None if skip_sh else alloc((P, M, 3), **f32)
         dL_dscales = alloc((P, 3), **f32)
         dL_drotations = alloc((P, 4), **f32)

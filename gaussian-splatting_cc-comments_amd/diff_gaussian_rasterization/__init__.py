@@ -112,8 +112,13 @@ class _RasterizeGaussians(torch.autograd.Function):
                 print("\nAn error occured in backward. Writing snapshot_bw.dump for debugging.\n")
                 raise ex
         else:
-            (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh,
-             grad_scales, grad_rotations) = _C.rasterize_gaussians_backward(*args)
+            # gradients of inputs that were not provided have no consumer below: the binding may skip them
+            prev, _C.ONLY_CONSUMED_GRADS = _C.ONLY_CONSUMED_GRADS, True
+            try:
+                (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh,
+                 grad_scales, grad_rotations) = _C.rasterize_gaussians_backward(*args)
+            finally:
+                _C.ONLY_CONSUMED_GRADS = prev
 
         # gradient order: reference __init__.py:154-164
         grads = (

@@ -143,6 +143,8 @@ int gsr_forward_render(
  *   dL_dpix [3][H][W]; outputs: dL_dmean2D [P][3], dL_dconic [P][4] (the reference's (P,2,2)),
  *   dL_dopacity [P], dL_dcolor [P][3], dL_dmean3D [P][3], dL_dcov3D [P][6], dL_dsh [P][M][3]
  *   (may be NULL when M == 0), dL_dscale [P][3], dL_drot [P][4].
+ * dL_dconic (an intermediate of the reference), dL_dcolor when the colours came from SH and dL_dcov3D
+ * when the covariances came from scales/rotations have no consumer: pass NULL to skip those writes.
  * View-parallel mode: with shs given and dL_dsh == NULL the SH gradient is not produced and
  * dL_dcolor receives dL/dRGB with the channels the forward clamped at 0 zeroed -- the 3 floats per
  * Gaussian that gsr_sh_grad_from_views() needs; every other output is unchanged.
