@@ -252,12 +252,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     # GSR_BENCH_BACKEND=gloo (debug only): lets several ranks share ONE GPU to rehearse the N > 1 code path
     backend = os.environ.get("GSR_BENCH_BACKEND", "nccl")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC for RCCL; must be set before the first HIP call
     if backend != "nccl":
         local_rank = local_rank % max(1, torch.cuda.device_count())
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)  # before any collective: RCCL binds the communicator to the current device
     if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
