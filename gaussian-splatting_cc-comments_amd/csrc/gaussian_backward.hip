@@ -179,7 +179,7 @@ __global__ void __launch_bounds__(256) gsr_gaussian_backward_kernel(GsrGaussianB
 
 	// ---- stage the wave's SH block (64 x 48 floats, contiguous in HBM) into LDS, coalesced ----
 	if (sh_via_lds && nrows > 0) {
-		if (LEAF) gsr_sh_rows_load_split(s_sh[wave], a.shs, a.shs_rest, wave_first, nrows, lane);
+		if (LEAF) gsr_sh_lin_load(reinterpret_cast<float*>(s_sh[wave]), a.shs, a.shs_rest, wave_first, nrows, lane);
 		else gsr_sh_rows_load(s_sh[wave], a.shs, wave_first, nrows, lane);
 	}
 
@@ -320,17 +320,26 @@ __global__ void __launch_bounds__(256) gsr_gaussian_backward_kernel(GsrGaussianB
 		if (a.shs) {
 			if (sh_via_lds) {
 				float shv[48];  // own row out of LDS into registers, then dL_dsh overwrites the row in place
+				if (LEAF) {
+					gsr_sh_lin_row_get(reinterpret_cast<const float*>(s_sh[wave]), lane, shv);
+				} else {
 #pragma unroll
-				for (int j = 0; j < 12; j++) {
-					const float4 v = s_sh[wave][lane * GSR_SH_ROW4 + j];
-					shv[4 * j] = v.x; shv[4 * j + 1] = v.y; shv[4 * j + 2] = v.z; shv[4 * j + 3] = v.w;
+					for (int j = 0; j < 12; j++) {
+						const float4 v = s_sh[wave][lane * GSR_SH_ROW4 + j];
+						shv[4 * j] = v.x; shv[4 * j + 1] = v.y; shv[4 * j + 2] = v.z; shv[4 * j + 3] = v.w;
+					}
 				}
 				// dL_dsh = basis x dL/dRGB is written below as 12 float4 (the row is conflict-free for 16-byte
 				// accesses; 48 scalar stores at this row stride hit 4-way bank conflicts)
 				float basis[16];
 				const int used_sh = (a.D + 1) * (a.D + 1);
 				gsr_sh_backward(a.D, M, mean, a.cam_pos, shv, a.g.clamped[idx], dcolor, dmean3D, nullptr, false, dRGB, basis);
-				if (!skip_dsh) {
+				if (!skip_dsh && LEAF) {
+					float o[48];
+#pragma unroll
+					for (int e = 0; e < 48; e++) o[e] = (e / 3 < used_sh) ? basis[e / 3] * dRGB[e % 3] : 0.f;
+					gsr_sh_lin_row_put(reinterpret_cast<float*>(s_sh[wave]), lane, o);
+				} else if (!skip_dsh) {
 #pragma unroll
 					for (int j = 0; j < 12; j++) {
 						float o[4];
@@ -374,12 +383,19 @@ __global__ void __launch_bounds__(256) gsr_gaussian_backward_kernel(GsrGaussianB
 		dcolor[0] = dRGB[0]; dcolor[1] = dRGB[1]; dcolor[2] = dRGB[2];
 	} else if (sh_via_lds) {
 		if (!visible) {
+			if (LEAF) {
+				float z[48];
 #pragma unroll
-			for (int j = 0; j < 12; j++) s_sh[wave][lane * GSR_SH_ROW4 + j] = make_float4(0.f, 0.f, 0.f, 0.f);
+				for (int e = 0; e < 48; e++) z[e] = 0.f;
+				gsr_sh_lin_row_put(reinterpret_cast<float*>(s_sh[wave]), lane, z);
+			} else {
+#pragma unroll
+				for (int j = 0; j < 12; j++) s_sh[wave][lane * GSR_SH_ROW4 + j] = make_float4(0.f, 0.f, 0.f, 0.f);
+			}
 		}
 		__builtin_amdgcn_wave_barrier();
 		if (nrows > 0) {
-			if (LEAF) gsr_sh_rows_store_split(s_sh[wave], a.dL_dsh, a.dL_dsh_rest, wave_first, nrows, lane);
+			if (LEAF) gsr_sh_lin_store(reinterpret_cast<const float*>(s_sh[wave]), a.dL_dsh, a.dL_dsh_rest, wave_first, nrows, lane);
 			else gsr_sh_rows_store(s_sh[wave], a.dL_dsh, wave_first, nrows, lane);
 		}
 	} else if (LEAF) {

@@ -178,17 +178,21 @@ __device__ __forceinline__ void gsr_sh_rows_store(const float4* __restrict__ row
 		if (f < nrows * 12) dst[f] = rows[(f / 12) * GSR_SH_ROW4 + (f % 12)];
 	}
 }
-// split leaf tensors _features_dc (P,1,3) + _features_rest (P,15,3) -> the same rows (the torch.cat of
-// gaussian_model.py:124-127 done on the fly)
-__device__ __forceinline__ void gsr_sh_rows_load_split(float4* __restrict__ rows4, const float* __restrict__ dc, const float* __restrict__ rest,
-                                                       int wave_first, int nrows, int lane)
+// Split leaf tensors _features_dc (P,1,3) + _features_rest (P,15,3) (the torch.cat of
+// gaussian_model.py:124-127 done on the fly).  The wave's two blocks are copied LINEARLY into LDS
+// (coalesced 16-byte global accesses, conflict-free ds_*_b128): floats [0, 64*45) = the _features_rest
+// block, [64*45, 64*48) = the _features_dc block.  A lane then reads / writes its own row with scalar LDS
+// accesses at strides 45 and 3 -- both odd, so the 32 banks are hit once each.  (Scattering the elements
+// into 48-float rows instead costs 4-way bank conflicts on every access: measured +20 us in preprocess.)
+#define GSR_SH_LIN_DC (64 * 45)
+__device__ __forceinline__ void gsr_sh_lin_load(float* __restrict__ lin, const float* __restrict__ dc, const float* __restrict__ rest,
+                                                int wave_first, int nrows, int lane)
 {
-	float* rows = reinterpret_cast<float*>(rows4);
 	const float* dcw = dc + (size_t)wave_first * 3;
 #pragma unroll
 	for (int i = 0; i < 3; i++) {
 		const int e = lane + 64 * i;
-		if (e < nrows * 3) rows[(e / 3) * GSR_SH_ROWF + e % 3] = dcw[e];
+		if (e < nrows * 3) lin[GSR_SH_LIN_DC + e] = dcw[e];
 	}
 	const float* rw = rest + (size_t)wave_first * 45;
 	const int n = nrows * 45;
@@ -196,41 +200,49 @@ __device__ __forceinline__ void gsr_sh_rows_load_split(float4* __restrict__ rows
 	for (int it = 0; it < 12; it++) {
 		const int e0 = (it * 64 + lane) * 4;
 		if (e0 + 3 < n) {
-			const float4 v = *reinterpret_cast<const float4*>(rw + e0);
-			const float vv[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-			for (int j = 0; j < 4; j++) { const int e = e0 + j; rows[(e / 45) * GSR_SH_ROWF + 3 + e % 45] = vv[j]; }
+			*reinterpret_cast<float4*>(lin + e0) = *reinterpret_cast<const float4*>(rw + e0);
 		} else {
 #pragma unroll
-			for (int j = 0; j < 4; j++) { const int e = e0 + j; if (e < n) rows[(e / 45) * GSR_SH_ROWF + 3 + e % 45] = rw[e]; }
+			for (int j = 0; j < 4; j++) if (e0 + j < n) lin[e0 + j] = rw[e0 + j];
 		}
 	}
 }
-__device__ __forceinline__ void gsr_sh_rows_store_split(const float4* __restrict__ rows4, float* __restrict__ dc, float* __restrict__ rest,
-                                                        int wave_first, int nrows, int lane)
+__device__ __forceinline__ void gsr_sh_lin_store(const float* __restrict__ lin, float* __restrict__ dc, float* __restrict__ rest,
+                                                 int wave_first, int nrows, int lane)
 {
-	const float* rows = reinterpret_cast<const float*>(rows4);
 	float* dcw = dc + (size_t)wave_first * 3;
 #pragma unroll
 	for (int i = 0; i < 3; i++) {
 		const int e = lane + 64 * i;
-		if (e < nrows * 3) dcw[e] = rows[(e / 3) * GSR_SH_ROWF + e % 3];
+		if (e < nrows * 3) dcw[e] = lin[GSR_SH_LIN_DC + e];
 	}
 	float* rw = rest + (size_t)wave_first * 45;
 	const int n = nrows * 45;
 #pragma unroll
 	for (int it = 0; it < 12; it++) {
 		const int e0 = (it * 64 + lane) * 4;
-		float vv[4];
-#pragma unroll
-		for (int j = 0; j < 4; j++) { const int e = min(e0 + j, 64 * 45 - 1); vv[j] = rows[(e / 45) * GSR_SH_ROWF + 3 + e % 45]; }
 		if (e0 + 3 < n) {
-			*reinterpret_cast<float4*>(rw + e0) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+			*reinterpret_cast<float4*>(rw + e0) = *reinterpret_cast<const float4*>(lin + e0);
 		} else {
 #pragma unroll
-			for (int j = 0; j < 4; j++) if (e0 + j < n) rw[e0 + j] = vv[j];
+			for (int j = 0; j < 4; j++) if (e0 + j < n) rw[e0 + j] = lin[e0 + j];
 		}
 	}
+}
+// the lane's own 16 x 3 coefficients (k-major: [3k + c]) out of / into the linear blocks
+__device__ __forceinline__ void gsr_sh_lin_row_get(const float* __restrict__ lin, int lane, float* __restrict__ row48)
+{
+#pragma unroll
+	for (int c = 0; c < 3; c++) row48[c] = lin[GSR_SH_LIN_DC + 3 * lane + c];
+#pragma unroll
+	for (int j = 0; j < 45; j++) row48[3 + j] = lin[45 * lane + j];
+}
+__device__ __forceinline__ void gsr_sh_lin_row_put(float* __restrict__ lin, int lane, const float* __restrict__ row48)
+{
+#pragma unroll
+	for (int c = 0; c < 3; c++) lin[GSR_SH_LIN_DC + 3 * lane + c] = row48[c];
+#pragma unroll
+	for (int j = 0; j < 45; j++) lin[45 * lane + j] = row48[3 + j];
 }
 
 // forward.cu:84-140 computeCov2D, also recomputed by backward.cu:144-199

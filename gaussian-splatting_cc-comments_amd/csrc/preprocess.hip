@@ -46,7 +46,7 @@ __global__ void __launch_bounds__(GSR_PREPROCESS_BLOCK) gsr_preprocess_kernel(Gs
 		const int wave_first = blockIdx.x * GSR_PREPROCESS_BLOCK + wave * 64;
 		const int nrows = min(64, a.P - wave_first);
 		if (nrows > 0) {
-			if (LEAF) gsr_sh_rows_load_split(s_sh[wave], a.shs, a.shs_rest, wave_first, nrows, lane);
+			if (LEAF) gsr_sh_lin_load(reinterpret_cast<float*>(s_sh[wave]), a.shs, a.shs_rest, wave_first, nrows, lane);
 			else gsr_sh_rows_load(s_sh[wave], a.shs, wave_first, nrows, lane);
 		}
 		__builtin_amdgcn_wave_barrier();
@@ -111,17 +111,28 @@ __global__ void __launch_bounds__(GSR_PREPROCESS_BLOCK) gsr_preprocess_kernel(Gs
 				dx = dx / len; dy = dy / len; dz = dz / len;
 				const float* sh = sh_via_lds ? reinterpret_cast<const float*>(&s_sh[threadIdx.x >> 6][(threadIdx.x & 63) * GSR_SH_ROW4])
 				                             : a.shs + (size_t)idx * a.M * 3;
-				float sh_local[48];
-				if (LEAF && !sh_via_lds) {  // generic M / unaligned leaves: gather the used rows
-					const int used = (a.D + 1) * (a.D + 1);
-					for (int k = 0; k < used; k++)
-						for (int ch = 0; ch < 3; ch++)
-							sh_local[k * 3 + ch] = k == 0 ? a.shs[3 * (size_t)idx + ch] : a.shs_rest[((size_t)idx * (a.M - 1) + (k - 1)) * 3 + ch];
-					sh = sh_local;
+				float raw[3];
+				if (LEAF && sh_via_lds) {
+					// own row into registers: only ever indexed with constants below, so it never touches scratch
+					float row[48];
+					gsr_sh_lin_row_get(reinterpret_cast<const float*>(s_sh[threadIdx.x >> 6]), threadIdx.x & 63, row);
+#pragma unroll
+					for (int ch = 0; ch < 3; ch++) raw[ch] = gsr_sh_channel(a.D, row, ch, dx, dy, dz);
+				} else {
+					float sh_local[48];
+					if (LEAF) {  // generic M / unaligned leaves: gather the used rows (scratch; rare path)
+						const int used = (a.D + 1) * (a.D + 1);
+						for (int k = 0; k < used; k++)
+							for (int ch = 0; ch < 3; ch++)
+								sh_local[k * 3 + ch] = k == 0 ? a.shs[3 * (size_t)idx + ch] : a.shs_rest[((size_t)idx * (a.M - 1) + (k - 1)) * 3 + ch];
+						sh = sh_local;
+					}
+#pragma unroll
+					for (int ch = 0; ch < 3; ch++) raw[ch] = gsr_sh_channel(a.D, sh, ch, dx, dy, dz);
 				}
 #pragma unroll
 				for (int ch = 0; ch < 3; ch++) {
-					float v = gsr_sh_channel(a.D, sh, ch, dx, dy, dz);
+					const float v = raw[ch];
 					if (v < 0) clamp_bits |= (uint8_t)(1u << ch);
 					rgb[ch] = fmaxf(v, 0.0f);
 				}
