@@ -500,8 +500,10 @@ __global__ void __launch_bounds__(256) gsr_sh_grad_from_views_kernel(int P, int 
 			}
 		}
 	} else if (in_range) {
-		float* out = dL_dsh + (size_t)idx * M * 3;
-		for (int i = 0; i < M * 3; i++) out[i] = (i < 48) ? acc[i] : 0.f;
+		float* out = dL_dsh + (size_t)idx * M * 3;  // M <= 16 (checked by the caller)
+#pragma unroll
+		for (int i = 0; i < 48; i++)  // constant indices only: a dynamic one would move `acc` to scratch for BOTH paths
+			if (i < M * 3) out[i] = acc[i];
 	}
 }
 
