@@ -280,6 +280,7 @@ static int gsr_forward_preprocess_impl(int P, int D, int M, int width, int heigh
 	if (!aligned16(geometry)) return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "geometry buffer must be 16-byte aligned");
 
 	if (leaf && (M > 1 && !shs_rest)) return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "leaf mode: features_rest is NULL");
+	if (leaf && M > 16) return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "leaf mode: at most 16 SH coefficients (degree 3), M = %d", M);
 	GsrPreprocessArgs a = {};
 	a.leaf = leaf; a.shs_rest = shs_rest;
 	a.P = P; a.D = D; a.M = M; a.W = width; a.H = height;
@@ -441,6 +442,7 @@ static int gsr_backward_impl(int P, int D, int M, int64_t R, int width, int heig
 	if (leaf) {
 		if (!shs || !scales || !rotations || (M > 1 && !shs_rest))
 			return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "gsr_backward_leaf: a leaf tensor is NULL");
+		if (M > 16) return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "gsr_backward_leaf: at most 16 SH coefficients (degree 3), M = %d", M);
 		if ((dL_dsh == nullptr) != (dL_dsh_rest == nullptr) && M > 1)
 			return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "gsr_backward_leaf: pass both feature gradients or neither");
 		if (!dL_dsh && !dL_dcolor)

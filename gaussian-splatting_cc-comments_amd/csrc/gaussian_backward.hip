@@ -351,10 +351,17 @@ __global__ void __launch_bounds__(256) gsr_gaussian_backward_kernel(GsrGaussianB
 				}
 			} else if (LEAF) {
 				const int used = (a.D + 1) * (a.D + 1);
-				for (int k = 0; k < used; k++)
-					for (int ch = 0; ch < 3; ch++)
-						sh_local[k * 3 + ch] = k == 0 ? a.shs[3 * (size_t)idx + ch] : a.shs_rest[((size_t)idx * (M - 1) + (k - 1)) * 3 + ch];
-				gsr_sh_backward(a.D, used, mean, a.cam_pos, sh_local, a.g.clamped[idx], dcolor, dmean3D, dsh_local, !skip_dsh, dRGB);
+#pragma unroll
+				for (int k = 0; k < 16; k++)  // constant indices (registers, no scratch); (D+1)^2 <= 16
+					if (k < used) {
+#pragma unroll
+						for (int ch = 0; ch < 3; ch++)
+							sh_local[k * 3 + ch] = k == 0 ? a.shs[3 * (size_t)idx + ch] : a.shs_rest[((size_t)idx * (M - 1) + (k - 1)) * 3 + ch];
+					}
+				float basis[16];
+				gsr_sh_backward(a.D, used, mean, a.cam_pos, sh_local, a.g.clamped[idx], dcolor, dmean3D, nullptr, false, dRGB, basis);
+#pragma unroll
+				for (int e = 0; e < 48; e++) dsh_local[e] = (e / 3 < used) ? basis[e / 3] * dRGB[e % 3] : 0.f;
 			} else {
 				gsr_sh_backward(a.D, M, mean, a.cam_pos, a.shs + (size_t)idx * M * 3, a.g.clamped[idx], dcolor, dmean3D, dsh_global,
 				                !skip_dsh, dRGB);
@@ -401,11 +408,15 @@ __global__ void __launch_bounds__(256) gsr_gaussian_backward_kernel(GsrGaussianB
 	} else if (LEAF) {
 		if (in_range) {
 			const int used = visible ? (a.D + 1) * (a.D + 1) : 0;
-			for (int k = 0; k < M; k++)
-				for (int ch = 0; ch < 3; ch++) {
-					const float v = k < used ? dsh_local[k * 3 + ch] : 0.f;
-					if (k == 0) a.dL_dsh[3 * (size_t)idx + ch] = v;
-					else a.dL_dsh_rest[((size_t)idx * (M - 1) + (k - 1)) * 3 + ch] = v;
+#pragma unroll
+			for (int k = 0; k < 16; k++)
+				if (k < M) {
+#pragma unroll
+					for (int ch = 0; ch < 3; ch++) {
+						const float v = k < used ? dsh_local[k * 3 + ch] : 0.f;
+						if (k == 0) a.dL_dsh[3 * (size_t)idx + ch] = v;
+						else a.dL_dsh_rest[((size_t)idx * (M - 1) + (k - 1)) * 3 + ch] = v;
+					}
 				}
 		}
 	} else if ((!visible || !a.shs) && dsh_global) {

@@ -120,11 +120,15 @@ __global__ void __launch_bounds__(GSR_PREPROCESS_BLOCK) gsr_preprocess_kernel(Gs
 					for (int ch = 0; ch < 3; ch++) raw[ch] = gsr_sh_channel(a.D, row, ch, dx, dy, dz);
 				} else {
 					float sh_local[48];
-					if (LEAF) {  // generic M / unaligned leaves: gather the used rows (scratch; rare path)
+					if (LEAF) {  // generic M / unaligned leaves: gather the used rows (rare path)
 						const int used = (a.D + 1) * (a.D + 1);
-						for (int k = 0; k < used; k++)
-							for (int ch = 0; ch < 3; ch++)
-								sh_local[k * 3 + ch] = k == 0 ? a.shs[3 * (size_t)idx + ch] : a.shs_rest[((size_t)idx * (a.M - 1) + (k - 1)) * 3 + ch];
+#pragma unroll
+						for (int k = 0; k < 16; k++)  // constant indices (registers, no scratch); (D+1)^2 <= 16
+							if (k < used) {
+#pragma unroll
+								for (int ch = 0; ch < 3; ch++)
+									sh_local[k * 3 + ch] = k == 0 ? a.shs[3 * (size_t)idx + ch] : a.shs_rest[((size_t)idx * (a.M - 1) + (k - 1)) * 3 + ch];
+							}
 						sh = sh_local;
 					}
 #pragma unroll
