@@ -39,11 +39,15 @@ class GradientBucket:
             off += p.numel()
 
     def pack(self):
-        for p, v in zip(self.params, self.views):
-            if p.grad is None:
+        grads = [p.grad for p in self.params]
+        if all(g is not None and g.data_ptr() != v.data_ptr() for g, v in zip(grads, self.views)):
+            torch.cat([g.reshape(-1) for g in grads], out=self.flat)  # one launch for all tensors
+            return
+        for g, v in zip(grads, self.views):
+            if g is None:
                 v.zero_()
-            else:
-                v.copy_(p.grad)
+            elif g.data_ptr() != v.data_ptr():  # already aliasing its slice (all_reduce() leaves p.grad = view)
+                v.copy_(g)
 
     def all_reduce(self, group: Optional[dist.ProcessGroup] = None, average: bool = False, async_op: bool = False):
         """Sum (or average) the packed gradients over all ranks; afterwards every p.grad aliases its
