@@ -234,3 +234,39 @@ def test_fused_adam_state_survives_densification_style_edits_and_visible_only_mo
         assert torch.equal(p.data[~vis], before[grp["name"]][0][~vis]), grp["name"]
         assert torch.equal(opt.state[p]["exp_avg"][~vis], before[grp["name"]][1][~vis]), grp["name"]
         assert torch.equal(p.data[vis], dense[grp["name"]][vis]), grp["name"]
+
+
+def test_leaf_mode_at_the_headline_size_is_bit_identical_in_the_forward():
+    """C3 (1M Gaussians, 1980x1080, degree 3): leaf mode vs PyTorch activations in front of the rasterizer --
+    identical radii and image, gradients within the bar, both runs bitwise reproducible."""
+    _need_gpu()
+    from diff_gaussian_rasterization import GaussianRasterizer
+    from fused_params import rasterize_leaf_gaussians
+    dev = torch.device("cuda:0")
+    P, W, H, D, mu = gsr_scene.CONFIGS["C3"]
+    scene = gsr_scene.make_scene(P, mu, D, seed=0)
+    cam = gsr_scene.make_camera(W, H)
+    st = util.hip_settings(scene, cam, D, dev)
+    dpix = torch.randn(3, H, W, generator=torch.Generator().manual_seed(1)).to(dev)
+
+    def run(leaf):
+        lv = _leaves(scene, dev, 3)
+        m2 = torch.zeros_like(lv["xyz"], requires_grad=True)
+        if leaf:
+            color, radii = rasterize_leaf_gaussians(lv["xyz"], m2, lv["features_dc"], lv["features_rest"], lv["opacity"], lv["scaling"],
+                                                    lv["rotation"], st)
+        else:
+            color, radii = GaussianRasterizer(st)(means2D=m2, **_activated(lv))
+        color.backward(dpix)
+        return color.detach(), radii, {k: v.grad for k, v in lv.items()}, m2.grad
+
+    c1, r1, g1, s1 = run(True)
+    c2, r2, g2, s2 = run(True)
+    assert torch.equal(c1, c2) and torch.equal(s1, s2) and all(torch.equal(g1[k], g2[k]) for k in g1)   # deterministic
+    c0, r0, g0, s0 = run(False)
+    assert torch.equal(r1, r0) and torch.equal(c1, c0)
+    assert torch.equal(s1, s0) and torch.equal(g1["xyz"], g0["xyz"])      # no activation in between: same bits
+    assert torch.equal(g1["features_dc"], g0["features_dc"]) and torch.equal(g1["features_rest"], g0["features_rest"])
+    for k in ("opacity", "scaling", "rotation"):
+        bar = GRAD_RTOL * float(g0[k].abs().max())
+        assert float((g1[k] - g0[k]).abs().max()) <= bar, (k, float((g1[k] - g0[k]).abs().max()), bar)
