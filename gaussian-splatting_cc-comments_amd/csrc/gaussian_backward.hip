@@ -165,16 +165,18 @@ __device__ __forceinline__ void gsr_add_slot(const GsrGradSlot* __restrict__ slo
 
 // LEAF: inputs are the optimiser's raw leaves and the outputs are gradients w.r.t. them: the backward
 // of exp / sigmoid / normalize / cat (gaussian_model.py:114-135) is applied in the epilogue.
+// workgroup = one wave: waves of a CU then start and retire independently (phases of different waves mix)
+#define GSR_GB_THREADS 64
 template <bool LEAF>
-__global__ void __launch_bounds__(256) gsr_gaussian_backward_kernel(GsrGaussianBackwardArgs a, int sh_via_lds, int skip_dsh)
+__global__ void __launch_bounds__(GSR_GB_THREADS) gsr_gaussian_backward_kernel(GsrGaussianBackwardArgs a, int sh_via_lds, int skip_dsh)
 {
-	__shared__ float4 s_sh[4][64 * GSR_SH_ROW4];
-	const int idx = blockIdx.x * 256 + threadIdx.x;
+	__shared__ float4 s_sh[GSR_GB_THREADS / 64][64 * GSR_SH_ROW4];
+	const int idx = blockIdx.x * GSR_GB_THREADS + threadIdx.x;
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	const int M = a.M;
 	const bool in_range = idx < a.P;
 	const bool visible = in_range && a.radii[idx] > 0;
-	const int wave_first = blockIdx.x * 256 + wave * 64;
+	const int wave_first = blockIdx.x * GSR_GB_THREADS + wave * 64;
 	const int nrows = min(64, a.P - wave_first);  // Gaussians of this wave (<= 0: none)
 
 	// ---- stage the wave's SH block (64 x 48 floats, contiguous in HBM) into LDS, coalesced ----
@@ -450,9 +452,9 @@ void gsr_launch_gaussian_backward(const GsrGaussianBackwardArgs& a, hipStream_t 
 	int sh_via_lds = (a.shs && a.M == 16 && ((uintptr_t)a.shs & 15u) == 0 && (skip_dsh || ((uintptr_t)a.dL_dsh & 15u) == 0)) ? 1 : 0;
 	if (a.leaf) {
 		if (((uintptr_t)a.shs_rest & 15u) != 0 || (!skip_dsh && ((uintptr_t)a.dL_dsh_rest & 15u) != 0)) sh_via_lds = 0;
-		hipLaunchKernelGGL(gsr_gaussian_backward_kernel<true>, dim3((a.P + 255) / 256), dim3(256), 0, s, a, sh_via_lds, skip_dsh);
+		hipLaunchKernelGGL(gsr_gaussian_backward_kernel<true>, dim3((a.P + GSR_GB_THREADS - 1) / GSR_GB_THREADS), dim3(GSR_GB_THREADS), 0, s, a, sh_via_lds, skip_dsh);
 	} else {
-		hipLaunchKernelGGL(gsr_gaussian_backward_kernel<false>, dim3((a.P + 255) / 256), dim3(256), 0, s, a, sh_via_lds, skip_dsh);
+		hipLaunchKernelGGL(gsr_gaussian_backward_kernel<false>, dim3((a.P + GSR_GB_THREADS - 1) / GSR_GB_THREADS), dim3(GSR_GB_THREADS), 0, s, a, sh_via_lds, skip_dsh);
 	}
 }
 
@@ -463,13 +465,13 @@ void gsr_launch_gaussian_backward(const GsrGaussianBackwardArgs& a, hipStream_t 
 // dL/dRGB of their views (12 B per Gaussian per view) and every rank runs this kernel.  Views are
 // added in index order with the products rounded first -- the sum a fixed-order all-reduce of the
 // per-view gradients would give.
-__global__ void __launch_bounds__(256) gsr_sh_grad_from_views_kernel(int P, int D, int M, int V, const float* __restrict__ means3D,
+__global__ void __launch_bounds__(GSR_GB_THREADS) gsr_sh_grad_from_views_kernel(int P, int D, int M, int V, const float* __restrict__ means3D,
                                                                       const float* __restrict__ cam_pos,
                                                                       const float* __restrict__ dL_dRGB, long long view_stride,
                                                                       float* __restrict__ dL_dsh, int via_lds)
 {
-	__shared__ float4 s_sh[4][64 * GSR_SH_ROW4];
-	const int idx = blockIdx.x * 256 + threadIdx.x;
+	__shared__ float4 s_sh[GSR_GB_THREADS / 64][64 * GSR_SH_ROW4];
+	const int idx = blockIdx.x * GSR_GB_THREADS + threadIdx.x;
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	const bool in_range = idx < P;
 	const int used = (D + 1) * (D + 1);
@@ -496,7 +498,7 @@ __global__ void __launch_bounds__(256) gsr_sh_grad_from_views_kernel(int P, int 
 		}
 	}
 	if (via_lds) {  // M == 16: coalesced float4 stream through an LDS transpose
-		const int wave_first = blockIdx.x * 256 + wave * 64;
+		const int wave_first = blockIdx.x * GSR_GB_THREADS + wave * 64;
 		const int nrows = min(64, P - wave_first);
 #pragma unroll
 		for (int j = 0; j < 12; j++)
@@ -522,6 +524,6 @@ void gsr_launch_sh_grad_from_views(int P, int D, int M, int V, const float* mean
                                    int64_t view_stride, float* dL_dsh, hipStream_t s)
 {
 	const int via_lds = (M == 16 && ((uintptr_t)dL_dsh & 15u) == 0) ? 1 : 0;
-	hipLaunchKernelGGL(gsr_sh_grad_from_views_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, D, M, V, means3D, cam_pos, dL_dRGB,
+	hipLaunchKernelGGL(gsr_sh_grad_from_views_kernel, dim3((P + GSR_GB_THREADS - 1) / GSR_GB_THREADS), dim3(GSR_GB_THREADS), 0, s, P, D, M, V, means3D, cam_pos, dL_dRGB,
 	                   (long long)view_stride, dL_dsh, via_lds);
 }
