@@ -132,7 +132,7 @@ extern "C" int gsr_geometry_layout_of(int P, gsr_geometry_layout* o)
 	o->perm_alt = off;       off = gsr_align_up(off + n * 4);
 	o->tiles_touched = off;  off = gsr_align_up(off + n * 4);
 	o->clamped = off;        off = gsr_align_up(off + n);
-	o->status = off;         off = gsr_align_up(off + 4 * 4);
+	o->status = off;         off = gsr_align_up(off + GSR_STATUS_WORDS * 4);
 	o->scan_temp = off;      off = gsr_align_up(off + 2 * gsr_align_up(nb * 4));
 	o->sort_table = off;     off = gsr_align_up(off + gsr_radix_table_bytes(n));
 	o->total = off;
@@ -295,18 +295,13 @@ static int gsr_forward_preprocess_impl(int P, int D, int M, int width, int heigh
 	a.g = gsr_geometry_view(geometry, P);
 
 	int rc;
-	if ((rc = gsr_check_hip(hipMemsetAsync(a.g.status, 0, 16, s), "hipMemsetAsync(status)"))) return rc;
+	if ((rc = gsr_check_hip(hipMemsetAsync(a.g.status, 0, GSR_STATUS_WORDS * 4, s), "hipMemsetAsync(status)"))) return rc;
 	{
 		GsrProfScope p(s, "preprocess");
 		gsr_launch_preprocess(a, s);
 	}
 	if ((rc = gsr_stage_done(s, debug, "preprocess"))) return rc;
 	const int nb = (P + GSR_PREPROCESS_BLOCK - 1) / GSR_PREPROCESS_BLOCK;
-	{
-		GsrProfScope p(s, "scan");
-		gsr_launch_scan_block_sums(a.g.block_sums, nb, a.g.status + 1, s);
-	}
-	if ((rc = gsr_stage_done(s, debug, "scan"))) return rc;
 
 	// read num_rendered back; the per-Gaussian half of the sort is enqueued behind the copy and keeps
 	// the GPU busy while the host waits on the event, allocates the binning buffer and launches stage 2
@@ -317,12 +312,12 @@ static int gsr_forward_preprocess_impl(int P, int D, int M, int width, int heigh
 	if ((rc = gsr_check_hip(hipGetDevice(&device), "hipGetDevice"))) return rc;
 	if (device < 0 || device >= GSR_MAX_DEVICES) return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "device index %d not supported", device);
 	if (!status_host_of[device]) {
-		if ((rc = gsr_check_hip(hipHostMalloc((void**)&status_host_of[device], 16, hipHostMallocDefault), "hipHostMalloc"))) return rc;
+		if ((rc = gsr_check_hip(hipHostMalloc((void**)&status_host_of[device], GSR_STATUS_WORDS * 4, hipHostMallocDefault), "hipHostMalloc"))) return rc;
 		if ((rc = gsr_check_hip(hipEventCreateWithFlags(&event_of[device], hipEventDisableTiming), "hipEventCreate"))) return rc;
 	}
 	uint32_t* status_host = status_host_of[device];
 	hipEvent_t ev = event_of[device];
-	if ((rc = gsr_check_hip(hipMemcpyAsync(status_host, a.g.status, 8, hipMemcpyDeviceToHost, s), "hipMemcpyAsync(num_rendered)"))) return rc;
+	if ((rc = gsr_check_hip(hipMemcpyAsync(status_host, a.g.status, GSR_STATUS_WORDS * 4, hipMemcpyDeviceToHost, s), "hipMemcpyAsync(num_rendered)"))) return rc;
 	if ((rc = gsr_check_hip(hipEventRecord(ev, s), "hipEventRecord"))) return rc;
 	{
 		GsrProfScope p(s, "depth_sort");
@@ -336,7 +331,9 @@ static int gsr_forward_preprocess_impl(int P, int D, int M, int width, int heigh
 	if ((rc = gsr_check_hip(hipEventSynchronize(ev), "hipEventSynchronize(num_rendered)"))) return rc;
 	if (status_host[0] & 1u)
 		return gsr_fail(GSR_ERR_PREFILTERED, "Point is filtered although prefiltered is set. This shouldn't happen!");
-	*num_rendered_host = (int64_t)status_host[1];
+	int64_t total = 0;
+	for (int k = 0; k < GSR_COUNT_PARTS; k++) total += (int64_t)status_host[4 + k];
+	*num_rendered_host = total;
 	return GSR_OK;
 }
 

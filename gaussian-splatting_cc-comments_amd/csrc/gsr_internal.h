@@ -8,6 +8,11 @@
 #include "gsr_device.h"
 
 #define GSR_PREPROCESS_BLOCK 256
+// The instance count (num_rendered) is accumulated by the preprocess workgroups with one atomic add each,
+// spread over this many words so that no address sees more than a few dozen (3 900 adds to ONE word cost
+// 9 us of serialisation); the host adds the parts after the read-back.
+#define GSR_COUNT_PARTS 64
+#define GSR_STATUS_WORDS (4 + GSR_COUNT_PARTS)
 
 static inline size_t gsr_align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
 static inline int gsr_grid_x(int W) { return (W + GSR_TILE_X - 1) / GSR_TILE_X; }
@@ -22,7 +27,8 @@ struct GsrGeometry {
 	uint32_t* perm_alt;
 	uint32_t* tiles_touched;
 	uint8_t* clamped;
-	uint32_t* status;             // [0] prefiltered trap, [1] num_rendered
+	uint32_t* status;             // [0] prefiltered trap, [4 .. 4+GSR_COUNT_PARTS) partial instance counts
+
 	uint32_t* block_sums;         // per-workgroup tile counts in original order (only their total is used)
 	uint32_t* sorted_block_sums;  // per-workgroup tile counts in depth order -> exclusive offsets
 	void* sort_table;             // radix histogram table for the P-sized depth sort

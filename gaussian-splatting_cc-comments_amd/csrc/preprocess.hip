@@ -158,7 +158,10 @@ __global__ void __launch_bounds__(GSR_PREPROCESS_BLOCK) gsr_preprocess_kernel(Gs
 		a.g.perm[idx] = (uint32_t)idx;
 	}
 
-	// workgroup sum of tiles_touched -> block_sums[blockIdx.x]
+	// workgroup sum of tiles_touched -> one atomic add into one of the partial instance counts (status words,
+	// zeroed by the host side before the launch; the host adds the parts): the count is all the forward needs from this order of the Gaussians -- the
+	// reference's inclusive scan over P (rasterizer_impl.cu:323) would give offsets in ORIGINAL order, and the
+	// offsets that are used here are those of the depth order (gsr_sorted_block_sums_kernel)
 	__shared__ uint32_t wsum[GSR_PREPROCESS_BLOCK / 64];
 	uint32_t v = tiles;
 #pragma unroll
@@ -169,7 +172,7 @@ __global__ void __launch_bounds__(GSR_PREPROCESS_BLOCK) gsr_preprocess_kernel(Gs
 		uint32_t t = 0;
 #pragma unroll
 		for (int w = 0; w < GSR_PREPROCESS_BLOCK / 64; w++) t += wsum[w];
-		a.g.block_sums[blockIdx.x] = t;
+		if (t) atomicAdd(&a.g.status[4 + (blockIdx.x & (GSR_COUNT_PARTS - 1))], t);
 	}
 }
 

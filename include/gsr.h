@@ -62,7 +62,7 @@ typedef struct {
 	size_t perm_alt;       /* [P] u32 sort ping-pong */
 	size_t tiles_touched;  /* [P] u32 */
 	size_t clamped;        /* [P] u8 bit c set = colour channel c was clamped at 0 */
-	size_t status;         /* [4] u32 device status words (0: prefiltered trap, 1: num_rendered) */
+	size_t status;         /* u32 device status words (0: prefiltered trap; 4..67: partial instance counts) */
 	size_t scan_temp;      /* per-workgroup tile counts: original order, then depth order */
 	size_t sort_table;     /* radix histogram table of the depth sort */
 	size_t total;
