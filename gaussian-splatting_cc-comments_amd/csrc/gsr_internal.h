@@ -7,7 +7,7 @@
 #include "../../include/gsr.h"
 #include "gsr_device.h"
 
-#define GSR_PREPROCESS_BLOCK 256
+#define GSR_PREPROCESS_BLOCK 256  // Gaussians per workgroup of the binning kernels (granularity of their scans)
 // The instance count (num_rendered) is accumulated by the preprocess workgroups with one atomic add each,
 // spread over this many words so that no address sees more than a few dozen (3 900 adds to ONE word cost
 // 9 us of serialisation); the host adds the parts after the read-back.
@@ -29,7 +29,7 @@ struct GsrGeometry {
 	uint8_t* clamped;
 	uint32_t* status;             // [0] prefiltered trap, [4 .. 4+GSR_COUNT_PARTS) partial instance counts
 
-	uint32_t* block_sums;         // per-workgroup tile counts in original order (only their total is used)
+	uint32_t* block_sums;         // (unused since the instance count moved into the status words)
 	uint32_t* sorted_block_sums;  // per-workgroup tile counts in depth order -> exclusive offsets
 	void* sort_table;             // radix histogram table for the P-sized depth sort
 };
