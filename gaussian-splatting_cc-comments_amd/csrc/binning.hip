@@ -151,25 +151,38 @@ void gsr_launch_duplicate_keys(GsrGeometry g, int P, int W, uint32_t* keys, uint
 }
 
 // ---- tile ranges (rasterizer_impl.cu:133-159; ranges zeroed first, :377) -------------------------
+// four consecutive instances per thread: one 16-byte load of the keys plus the key in front of them
 __global__ void __launch_bounds__(256) gsr_tile_ranges_kernel(const uint32_t* __restrict__ tile_keys, int64_t L, uint2* ranges)
 {
-	const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-	if (idx >= L) return;
-	const uint32_t currtile = tile_keys[idx];
-	if (idx == 0) ranges[currtile].x = 0;
-	else {
-		const uint32_t prevtile = tile_keys[idx - 1];
-		if (currtile != prevtile) {
+	const int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+	if (i0 >= L) return;
+	uint32_t k[4];
+	if (i0 + 3 < L) {
+		const uint4 v = *reinterpret_cast<const uint4*>(tile_keys + i0);  // the array is 256-byte aligned inside the blob
+		k[0] = v.x; k[1] = v.y; k[2] = v.z; k[3] = v.w;
+	} else {
+#pragma unroll
+		for (int j = 0; j < 4; j++) k[j] = (i0 + j < L) ? tile_keys[i0 + j] : 0u;
+	}
+	uint32_t prevtile = (i0 > 0) ? tile_keys[i0 - 1] : 0u;
+#pragma unroll
+	for (int j = 0; j < 4; j++) {
+		const int64_t idx = i0 + j;
+		if (idx >= L) break;
+		const uint32_t currtile = k[j];
+		if (idx == 0) ranges[currtile].x = 0;
+		else if (currtile != prevtile) {
 			ranges[prevtile].y = (uint32_t)idx;
 			ranges[currtile].x = (uint32_t)idx;
 		}
+		if (idx == L - 1) ranges[currtile].y = (uint32_t)L;
+		prevtile = currtile;
 	}
-	if (idx == L - 1) ranges[currtile].y = (uint32_t)L;
 }
 
 void gsr_launch_tile_ranges(const uint32_t* tile_keys, int64_t R, uint2* ranges, int ntiles, hipStream_t s)
 {
 	(void)hipMemsetAsync(ranges, 0, (size_t)ntiles * sizeof(uint2), s);
 	if (R > 0)
-		hipLaunchKernelGGL(gsr_tile_ranges_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, s, tile_keys, R, ranges);
+		hipLaunchKernelGGL(gsr_tile_ranges_kernel, dim3((unsigned)((R + 1023) / 1024)), dim3(256), 0, s, tile_keys, R, ranges);
 }
