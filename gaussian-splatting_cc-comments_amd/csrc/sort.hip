@@ -41,11 +41,28 @@ __global__ void __launch_bounds__(GSR_SORT_THREADS) gsr_radix_hist_kernel(const 
 	__shared__ uint32_t hist[GSR_SORT_RADIX];
 	hist[threadIdx.x] = 0;
 	__syncthreads();
-	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+	// the histogram does not care which thread counts which element of the block's tile: 16-byte loads
+	constexpr int TILE = GSR_SORT_THREADS * ITEMS;
+	const size_t first = (size_t)blockIdx.x * TILE;
+	if (first + TILE <= n) {
+		const uint4* src = reinterpret_cast<const uint4*>(keys + first);  // tile starts are multiples of 1024 elements
+		uint4 v[ITEMS / 4];
 #pragma unroll
-	for (int it = 0; it < ITEMS; it++) {
-		const size_t i = gsr_sort_index<ITEMS>(blockIdx.x, wave, it, lane);
-		if (i < n) atomicAdd(&hist[(keys[i] >> shift) & mask], 1u);
+		for (int it = 0; it < ITEMS / 4; it++) v[it] = src[it * GSR_SORT_THREADS + threadIdx.x];
+#pragma unroll
+		for (int it = 0; it < ITEMS / 4; it++) {
+			atomicAdd(&hist[(v[it].x >> shift) & mask], 1u);
+			atomicAdd(&hist[(v[it].y >> shift) & mask], 1u);
+			atomicAdd(&hist[(v[it].z >> shift) & mask], 1u);
+			atomicAdd(&hist[(v[it].w >> shift) & mask], 1u);
+		}
+	} else {
+		const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+		for (int it = 0; it < ITEMS; it++) {
+			const size_t i = gsr_sort_index<ITEMS>(blockIdx.x, wave, it, lane);
+			if (i < n) atomicAdd(&hist[(keys[i] >> shift) & mask], 1u);
+		}
 	}
 	__syncthreads();
 	table[(size_t)threadIdx.x * nblocks + blockIdx.x] = hist[threadIdx.x];  // [digit][block]
