@@ -151,8 +151,11 @@ void gsr_launch_duplicate_keys(GsrGeometry g, int P, int W, uint32_t* keys, uint
 }
 
 // ---- tile ranges (rasterizer_impl.cu:133-159; ranges zeroed first, :377) -------------------------
-// four consecutive instances per thread: one 16-byte load of the keys plus the key in front of them
-__global__ void __launch_bounds__(256) gsr_tile_ranges_kernel(const uint32_t* __restrict__ tile_keys, int64_t L, uint2* ranges)
+// four consecutive instances per thread: one 16-byte load of the keys plus the key in front of them.
+// Tiles without instances get (0,0) from the thread that sees the gap in the key sequence (the reference
+// zeroes the whole array first, rasterizer_impl.cu:377): every element of `ranges` is written exactly once.
+__global__ void __launch_bounds__(256) gsr_tile_ranges_kernel(const uint32_t* __restrict__ tile_keys, int64_t L, uint2* ranges,
+                                                              uint32_t ntiles)
 {
 	const int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
 	if (i0 >= L) return;
@@ -170,19 +173,27 @@ __global__ void __launch_bounds__(256) gsr_tile_ranges_kernel(const uint32_t* __
 		const int64_t idx = i0 + j;
 		if (idx >= L) break;
 		const uint32_t currtile = k[j];
-		if (idx == 0) ranges[currtile].x = 0;
-		else if (currtile != prevtile) {
+		if (idx == 0) {
+			for (uint32_t t = 0; t < currtile; t++) ranges[t] = make_uint2(0u, 0u);
+			ranges[currtile].x = 0;
+		} else if (currtile != prevtile) {
 			ranges[prevtile].y = (uint32_t)idx;
+			for (uint32_t t = prevtile + 1; t < currtile; t++) ranges[t] = make_uint2(0u, 0u);
 			ranges[currtile].x = (uint32_t)idx;
 		}
-		if (idx == L - 1) ranges[currtile].y = (uint32_t)L;
+		if (idx == L - 1) {
+			ranges[currtile].y = (uint32_t)L;
+			for (uint32_t t = currtile + 1; t < ntiles; t++) ranges[t] = make_uint2(0u, 0u);
+		}
 		prevtile = currtile;
 	}
 }
 
 void gsr_launch_tile_ranges(const uint32_t* tile_keys, int64_t R, uint2* ranges, int ntiles, hipStream_t s)
 {
-	(void)hipMemsetAsync(ranges, 0, (size_t)ntiles * sizeof(uint2), s);
 	if (R > 0)
-		hipLaunchKernelGGL(gsr_tile_ranges_kernel, dim3((unsigned)((R + 1023) / 1024)), dim3(256), 0, s, tile_keys, R, ranges);
+		hipLaunchKernelGGL(gsr_tile_ranges_kernel, dim3((unsigned)((R + 1023) / 1024)), dim3(256), 0, s, tile_keys, R, ranges,
+		                   (uint32_t)ntiles);
+	else
+		(void)hipMemsetAsync(ranges, 0, (size_t)ntiles * sizeof(uint2), s);
 }
