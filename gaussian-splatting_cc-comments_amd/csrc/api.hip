@@ -186,7 +186,7 @@ extern "C" size_t gsr_backward_scratch_bytes(int P, int64_t R)
 {
 	(void)P;
 	if (R < 0) return 0;
-	return gsr_align_up((size_t)R * sizeof(GsrGradSlot)) + gsr_align_up((size_t)R);
+	return gsr_align_up((size_t)R * sizeof(GsrGradSlot));
 }
 
 GsrGeometry gsr_geometry_view(void* blob, int P)
@@ -404,7 +404,7 @@ extern "C" int gsr_forward_render(int P, int64_t R, int width, int height, const
 	}
 	{
 		GsrProfScope p(s, "tile_ranges");
-		gsr_launch_tile_ranges(b.tile_keys, R, im.ranges, ntiles, s);
+		gsr_launch_tile_ranges(b.tile_keys, R, im.ranges, ntiles, b.tile_keys_alt, s);
 	}
 	if ((rc = gsr_stage_done(s, debug, "tile_ranges"))) return rc;
 	{
@@ -451,13 +451,16 @@ static int gsr_backward_impl(int P, int D, int M, int64_t R, int width, int heig
 	GsrGeometry g = gsr_geometry_view(geometry, P);
 	GsrImage im = gsr_image_view(image, width, height);
 	GsrGradSlot* slots = (GsrGradSlot*)scratch;
-	uint8_t* slot_valid = (uint8_t*)scratch + gsr_align_up((size_t)R * sizeof(GsrGradSlot));
+	// Validity bytes of the slots: the tile sort's dead ping-pong buffer, cleared at the end of the forward.
+	// Which slots get written depends on the forward alone (not on dL_dpix), so a second backward over the
+	// same forward state (retain_graph) finds exactly the bytes it would set itself.
+	uint8_t* slot_valid = nullptr;
 	int rc;
 	if (R > 0) {
 		GsrBinning b = gsr_binning_view(binning, P, R, width, height);
+		slot_valid = (uint8_t*)b.tile_keys_alt;
 		{
 			GsrProfScope p(s, "render_backward");
-			if ((rc = gsr_check_hip(hipMemsetAsync(slot_valid, 0, (size_t)R, s), "hipMemsetAsync(slot_valid)"))) return rc;
 			gsr_launch_render_backward(width, height, im, b.point_list, g.splat, background, dL_dpix, slots, slot_valid, s);
 		}
 		if ((rc = gsr_stage_done(s, debug, "render_backward"))) return rc;

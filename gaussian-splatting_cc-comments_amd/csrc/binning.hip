@@ -154,11 +154,14 @@ void gsr_launch_duplicate_keys(GsrGeometry g, int P, int W, uint32_t* keys, uint
 // four consecutive instances per thread: one 16-byte load of the keys plus the key in front of them.
 // Tiles without instances get (0,0) from the thread that sees the gap in the key sequence (the reference
 // zeroes the whole array first, rasterizer_impl.cu:377): every element of `ranges` is written exactly once.
+// Also clears the per-instance validity bytes of the backward pass (`valid`, one byte per instance = one
+// dword per thread here): they live in the sort's ping-pong buffer, which is dead once the sort has finished.
 __global__ void __launch_bounds__(256) gsr_tile_ranges_kernel(const uint32_t* __restrict__ tile_keys, int64_t L, uint2* ranges,
-                                                              uint32_t ntiles)
+                                                              uint32_t ntiles, uint32_t* __restrict__ valid)
 {
 	const int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
 	if (i0 >= L) return;
+	valid[i0 >> 2] = 0u;
 	uint32_t k[4];
 	if (i0 + 3 < L) {
 		const uint4 v = *reinterpret_cast<const uint4*>(tile_keys + i0);  // the array is 256-byte aligned inside the blob
@@ -189,11 +192,11 @@ __global__ void __launch_bounds__(256) gsr_tile_ranges_kernel(const uint32_t* __
 	}
 }
 
-void gsr_launch_tile_ranges(const uint32_t* tile_keys, int64_t R, uint2* ranges, int ntiles, hipStream_t s)
+void gsr_launch_tile_ranges(const uint32_t* tile_keys, int64_t R, uint2* ranges, int ntiles, uint32_t* valid, hipStream_t s)
 {
 	if (R > 0)
 		hipLaunchKernelGGL(gsr_tile_ranges_kernel, dim3((unsigned)((R + 1023) / 1024)), dim3(256), 0, s, tile_keys, R, ranges,
-		                   (uint32_t)ntiles);
+		                   (uint32_t)ntiles, valid);
 	else
 		(void)hipMemsetAsync(ranges, 0, (size_t)ntiles * sizeof(uint2), s);
 }

@@ -45,7 +45,7 @@ struct GsrBinning {
 	uint32_t* point_list;      // sorted Gaussian ids (final)
 	uint32_t* point_list_alt;  // ping-pong partner
 	uint32_t* tile_keys;       // sorted tile ids (final)
-	uint32_t* tile_keys_alt;
+	uint32_t* tile_keys_alt;   // after the forward: [R] validity BYTES of the backward's gradient slots (zeroed by tile_ranges)
 	void* sort_table;          // radix histogram table for the R-sized tile sort
 };
 
@@ -100,7 +100,7 @@ void gsr_launch_mark_visible(int P, const float* means3D, const float* viewmatri
 void gsr_launch_scan_block_sums(uint32_t* block_sums, int nb, uint32_t* total_out, hipStream_t s);
 void gsr_launch_sorted_block_sums(GsrGeometry g, int P, hipStream_t s);
 void gsr_launch_duplicate_keys(GsrGeometry g, int P, int W, uint32_t* keys, uint32_t* vals, hipStream_t s);
-void gsr_launch_tile_ranges(const uint32_t* tile_keys, int64_t R, uint2* ranges, int ntiles, hipStream_t s);
+void gsr_launch_tile_ranges(const uint32_t* tile_keys, int64_t R, uint2* ranges, int ntiles, uint32_t* valid, hipStream_t s);
 
 // sort.hip
 int gsr_radix_num_passes(int nbits_total);

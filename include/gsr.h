@@ -50,7 +50,7 @@ size_t gsr_geometry_bytes(int P);
 size_t gsr_image_bytes(int width, int height);
 size_t gsr_binning_bytes(int P, int64_t num_rendered, int width, int height);
 /* Scratch for one gsr_backward() call: [R] 48-byte per-(Gaussian,tile) gradient records written
- * by the backward blend + [R] validity bytes.  Not kept after the call. */
+ * by the backward blend.  Not kept after the call. */
 size_t gsr_backward_scratch_bytes(int P, int64_t num_rendered);
 
 /* Byte offsets of the typed arrays inside each blob (introspection for tests / debuggers). */
@@ -80,7 +80,7 @@ typedef struct {
 	size_t point_list;     /* [R] u32 Gaussian ids sorted by (tile, depth, id) -- the reference's point_list */
 	size_t point_list_alt; /* [R] u32 sort ping-pong */
 	size_t tile_keys;      /* [R] u32 tile id of each sorted instance (the high word of the reference's key) */
-	size_t tile_keys_alt;  /* [R] u32 sort ping-pong */
+	size_t tile_keys_alt;  /* [R] u32 sort ping-pong; after the forward its first R bytes are the backward's slot validity flags */
 	size_t sort_table;     /* radix histogram table of the tile sort */
 	size_t total;
 } gsr_binning_layout;

@@ -180,3 +180,37 @@ def test_view_parallel_compact_sh_gradient_equals_sum_of_per_view_gradients():
         # single-process form of the exchange (world size 1)
         one = view_parallel.exchange_sh_gradient(scene.means3D.to(dev), cam_all[0], rgb_all[0], D, M)
         assert torch.equal(one, ref[0]["shs"].grad)
+
+
+def test_backward_twice_over_the_same_forward_state():
+    """retain_graph: the backward reads the forward's state buffers (and the slot validity bytes that live in
+    the sort's ping-pong buffer) a second time -- with a DIFFERENT upstream gradient -- and must give exactly
+    what a fresh forward + backward gives for that gradient."""
+    _need_gpu()
+    from diff_gaussian_rasterization import GaussianRasterizer
+    dev = torch.device("cuda:0")
+    scene = gsr_scene.make_scene(7000, -3.0, sh_degree=3, seed=17)
+    cam = gsr_scene.ring_camera(256, 144, 4, 8)
+    st = util.hip_settings(scene, cam, 3, dev)
+    g = torch.Generator().manual_seed(4)
+    d1 = torch.randn(3, 144, 256, generator=g).to(dev)
+    d2 = torch.randn(3, 144, 256, generator=g).to(dev) * (torch.rand(3, 144, 256, generator=g).to(dev) > 0.5)   # zeros on half of the pixels
+    names = ("means3D", "shs", "opacities", "scales", "rotations")
+
+    def fresh():
+        p = {k: getattr(scene, k).to(dev).clone().requires_grad_(True) for k in names}
+        color, _ = GaussianRasterizer(st)(means2D=torch.zeros_like(p["means3D"], requires_grad=True), **p)
+        return p, color
+
+    p, color = fresh()
+    color.backward(d1, retain_graph=True)
+    first = {k: p[k].grad.clone() for k in names}
+    for k in names:
+        p[k].grad = None
+    color.backward(d2)
+    second = {k: p[k].grad.clone() for k in names}
+    q, color2 = fresh()
+    color2.backward(d2)
+    for k in names:
+        assert torch.equal(second[k], q[k].grad), k
+        assert not torch.equal(first[k], second[k]), k
