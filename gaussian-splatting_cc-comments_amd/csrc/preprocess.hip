@@ -3,8 +3,8 @@
 // Replaces preprocessCUDA (cuda_rasterizer/forward.cu:192-324) and checkFrustum
 // (cuda_rasterizer/rasterizer_impl.cu:56-69).  One Gaussian per lane, 256-thread workgroups.
 // Outputs go into one 48-byte splat record per Gaussian instead of five separate arrays, and the
-// kernel also emits the per-workgroup sum of tiles_touched so the prefix sum that follows needs
-// no extra pass over P.
+// kernel also accumulates the instance count (num_rendered) -- one atomic add per workgroup into 64
+// partial counters -- so no scan over P follows.
 #include "gsr_internal.h"
 
 // forward.cu:21-81 computeColorFromSH, one channel at a time in the glm::vec3 expression order
