@@ -63,3 +63,19 @@ def test_random_configuration_matches_oracle(seed):
     check_grads(h, o, dpix, ["dL_dmeans3D", "dL_dmeans2D", "dL_dopacity", "dL_dsh", "dL_dscales", "dL_drotations"])
     print(f"seed {seed}: {W}x{H} D{D} P{P} inside={inside} R={o['num_rendered']} max radius {int(o['radii'].max())} "
           f"fov {math.degrees(2 * math.atan(cam.tanfovx)):.0f} deg")
+
+
+@pytest.mark.parametrize("P,W,H,D", [(1, 1, 1, 0), (1, 33, 17, 3), (5, 1, 40, 1), (64, 16, 16, 2), (65, 17, 1, 0), (257, 31, 47, 3)])
+def test_tiny_and_degenerate_sizes_match_oracle(P, W, H, D):
+    """One Gaussian, one pixel, one-pixel-wide images, exactly one tile, P just over a wave / a workgroup."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    scene = gsr_scene.make_scene(P, -1.5, sh_degree=D, seed=P + W)
+    scene = scene._replace(means3D=scene.means3D * 0.3)   # keep them in front of the camera and on screen
+    cam = gsr_scene.make_camera(W, H)
+    o = util.oracle_forward(scene, cam, D)
+    dpix = util.fragile_free_dpix(o, cam, seed=3)
+    h = util.hip_forward_backward(scene, cam, D, dpix)
+    check_forward(h, o, cam)
+    if o["num_rendered"] > 0:
+        check_grads(h, o, dpix, ["dL_dmeans3D", "dL_dmeans2D", "dL_dopacity", "dL_dsh", "dL_dscales", "dL_drotations"])
