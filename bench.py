@@ -1,12 +1,13 @@
 """Benchmark of the rasterizer hot path: train iters/sec (fwd+bwd rasterize) @1980x1080, 1M Gaussians.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config C3]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config C3]      (N > 1: starts N ranks itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 One "step" = one forward + one backward of the drop-in GaussianRasterizer over one synthetic view
 (inputs resident in HBM).  With N > 1 every rank renders its own view of the replicated scene and
-the per-step parameter gradients (59 floats per Gaussian) are summed with ONE RCCL all-reduce of a
-flat bucket; value = views per second over all ranks (weak scaling).  Prints ONE JSON line on rank 0.
+the per-step parameter gradients (59 floats per Gaussian) are summed over the ranks inside the backward
+(view_parallel.rasterize_view_parallel: RCCL collectives per part of the per-Gaussian backward, overlapped
+with the next part); value = views per second over all ranks (weak scaling).  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
@@ -29,13 +30,19 @@ import gsr_scene  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, corrected as
 # MI355X_MICROARCH.md "HBM" prescribes) of this same command, summarised by tools/pmc_summary.py
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r1_pmc_summary.json")
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r2_pmc_summary.json")
+if not os.path.exists(PMC_SUMMARY):
+    PMC_SUMMARY = os.path.join(ROOT, "profiles", "r1_pmc_summary.json")
 KERNEL_SYMBOL = {"render_backward": "gsr_render_backward_wave_kernel", "render_forward": "gsr_render_forward_wave_kernel",
                  "gaussian_backward": "gsr_gaussian_backward_kernel", "preprocess": "gsr_preprocess_kernel",
                  "duplicate_keys": "gsr_duplicate_keys_kernel", "tile_ranges": "gsr_tile_ranges_kernel"}
 
 
 DOMINANT_STAGE = "render_backward"   # the kernel with the largest launch time in every configuration measured
+# share of transcendental instructions (v_exp_f32 / v_rcp_f32 / v_log_f32: 8 issue cycles instead of 4) among the VALU
+# instructions of the blend kernels' inner loops, counted in the ISA (used when the PMC summary has no
+# SQ_INSTS_VALU_TRANS_F32 for the kernel)
+TRANS_SHARE = {"render_backward": 0.065, "render_forward": 0.06}
 
 
 def _pmc_entry(stage, workload):
@@ -53,18 +60,6 @@ def pmc_traffic(stage, workload):
     try:
         return _pmc_entry(stage, workload).get("hbm_traffic_bytes")
     except (OSError, KeyError, ValueError):
-        return None
-
-
-def pmc_valu_issue(stage, workload):
-    """Fraction of the SIMDs' VALU issue capacity the kernel used, from the committed PMC summary:
-    SQ_ACTIVE_INST_VALU counts quad-cycles summed over waves, SQ_BUSY_CYCLES counts cycles summed over the 32
-    shader engines, 1024 SIMDs: 4 * ACTIVE / (BUSY / 32 * 1024) = ACTIVE / (8 * BUSY).  (Transcendentals issue
-    beside the main pipe, so a kernel full of v_exp/v_rcp can read slightly above 1.)"""
-    try:
-        e = _pmc_entry(stage, workload)
-        return round(e["SQ_ACTIVE_INST_VALU"] / (8.0 * e["SQ_BUSY_CYCLES"]), 3)
-    except (OSError, KeyError, ValueError, ZeroDivisionError):
         return None
 
 
@@ -115,6 +110,41 @@ def cpu_baseline(scene, cam, D):
     dt = time.time() - t0
     return dict(value=1.0 / dt, unit="it/s", cores=cores, kind="port",
                 sample="1 full fwd+bwd step of the same workload (C oracle, OpenMP, all host cores)"), o
+
+
+def cpu_baseline_torch():
+    """The CPU baseline north_star names: a PyTorch autograd splat on the box's host cores, at BASELINE.json
+    configs[0] (C1: 10k Gaussians, SH degree 0, 256x256, one view) -- oracle/torch_tile_splat.py, fp32, all cores."""
+    from oracle import torch_tile_splat
+    cores = host_cores()
+    scene, cam, D = gsr_scene.make_config("C1")
+    t, R, _ = torch_tile_splat.time_forward_backward(scene, cam, D, repeats=5, threads=cores)
+    return dict(value=round(1.0 / t, 4), unit="it/s", cores=cores, kind="port",
+                sample=f"C1 (10000 Gaussians, SH deg 0, 256x256, R={R}): fwd+bwd through torch.autograd, median of 5, "
+                       f"torch.set_num_threads({cores}); NOT the headline workload (C3 needs ~160x the pair evaluations)")
+
+
+def parity_figures(o, color, params, dpix, rasterizer, H, W):
+    """What the parity bars leave out, made visible: the oracle flags pixels whose accept/reject decisions sit within
+    2e-5 of a threshold ("fragile": a 1-ulp exp difference may flip alpha < 1/255 or T(1-alpha) < 1e-4 there); the
+    tests compare images on the others and zero the upstream gradient on the fragile ones."""
+    import numpy as np
+    from oracle import oracle
+    ok = (o["fragile"] == 0).reshape(H, W)
+    diff = np.abs(color.detach().cpu().numpy() - o["color"])
+    fig = dict(image_L1=float(diff.mean()), image_maxabs_nonfragile=float(diff[:, ok].max()),
+               image_maxabs_all_pixels=float(diff.max()), fragile_pixel_fraction=float(1.0 - ok.mean()))
+    og = oracle.backward(o, dpix.cpu().numpy())   # UNMASKED upstream gradient: fragile pixels included
+    names = dict(means3D="dL_dmeans3D", shs="dL_dsh", opacities="dL_dopacity", scales="dL_dscales", rotations="dL_drotations")
+    for p in params.values():
+        p.grad = None
+    means2D = torch.zeros_like(params["means3D"], requires_grad=True)
+    c, _ = rasterizer(means3D=params["means3D"], means2D=means2D, **{k: v for k, v in params.items() if k != "means3D"})
+    c.backward(dpix)
+    torch.cuda.synchronize()
+    fig["grad_relerr_unmasked_dpix"] = {k: float(np.abs(params[k].grad.cpu().numpy().reshape(-1) - og[n].reshape(-1)).max() /
+                                                 max(np.abs(og[n]).max(), 1e-30)) for k, n in names.items()}
+    return fig
 
 
 def bench_loss(image, dev, iters=20):
@@ -233,7 +263,7 @@ def bench_train_step(scene, settings, D, dev, iters=10):
                                           "parameters move, so V and R drift slightly from the headline workload")
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -244,182 +274,323 @@ def main():
     ap.add_argument("--no-train-step", action="store_true", help="skip the whole-training-iteration extra (8f rows)")
     ap.add_argument("--sh-exchange", default="compact", choices=["compact", "allreduce"],
                     help="N > 1: 'compact' all-gathers 3 floats/Gaussian/view and rebuilds the summed SH gradient "
-                         "locally (view_parallel.exchange_sh_gradient); 'allreduce' sums all 59 floats/Gaussian")
-    args = ap.parse_args()
+                         "locally (view_parallel.GradientExchange); 'allreduce' sums all 59 floats/Gaussian.  The timed "
+                         "region uses this mode; the other one is timed afterwards and reported under 'alt_exchange'")
+    ap.add_argument("--parts", type=int, default=2, help="N > 1: parts of the per-Gaussian backward whose exchange is "
+                                                         "started while the next part computes")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="rehearsal of the N > 1 plumbing WITHOUT the rasterizer (no GPU needed): ranks are spawned, the "
+                         "process group is formed and every step runs only the gradient exchange on synthetic buffers")
+    return ap.parse_args()
 
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N child ranks of this same script (one per GPU) and
+    relay rank 0's JSON line.  This parent never makes a HIP call and never re-execs: the children are fresh
+    processes that initialise the GPU themselves."""
+    import subprocess
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    try:
+        for p in procs:
+            code = p.wait()
+            if code != 0 and rc == 0:
+                rc = code
+                for q in procs:   # one rank failed: the others would wait in a collective forever
+                    if q.poll() is None:
+                        q.terminate()
+    finally:
+        for q in procs:
+            if q.poll() is None:
+                q.kill()
+    return rc
+
+
+def step_stats(ms):
+    ms = sorted(ms)
+    n = len(ms)
+    if n == 0:
+        return None
+    med = ms[n // 2] if n % 2 else 0.5 * (ms[n // 2 - 1] + ms[n // 2])
+    return dict(min=round(ms[0], 4), median=round(med, 4), max=round(ms[-1], 4), n=n)
+
+
+def valu_issue_fraction(stage, workload, avg_ms):
+    """Fraction of the chip's VALU issue capacity the kernel used during its launch, from SQ_INSTS_VALU of the committed
+    PMC summary and the issue costs measured on MI355X with tools/valu_probe.hip (profiles/r2_valu_probe.txt): one
+    SIMD issues one wave64 VALU instruction per 4 cycles whatever the number of waves (3.85-4.3 measured; fma, pk_fma,
+    dpp, cndmask alike), a transcendental (v_exp/v_rcp/...) holds it for 8.  1024 SIMDs; clock = the kernel's own
+    (SQ_BUSY_CYCLES is summed over the 32 shader engines).  By construction <= 1."""
+    try:
+        e = _pmc_entry(stage, workload)
+        insts = e["SQ_INSTS_VALU"]
+        trans = e.get("SQ_INSTS_VALU_TRANS_F32", TRANS_SHARE.get(stage, 0.0) * insts)
+        clock_hz = e["SQ_BUSY_CYCLES"] / 32.0 / (e.get("kernel_ms", avg_ms) * 1e-3)
+        cycles = 4.0 * (insts - trans) + 8.0 * trans
+        return dict(frac=round(cycles / (1024.0 * avg_ms * 1e-3 * clock_hz), 3), clock_GHz=round(clock_hz / 1e9, 3),
+                    valu_insts=int(insts), transcendental_insts=int(trans), cycles_per_inst=4.0, cycles_per_transcendental=8.0,
+                    simds=1024, source=os.path.basename(PMC_SUMMARY))
+    except (OSError, KeyError, ValueError, ZeroDivisionError):
+        return None
+
+
+def main():
+    args = parse_args()
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus))
+    world = int(env_world or "1")
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks; pass --gpus {world}")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     # GSR_BENCH_BACKEND=gloo (debug only): lets several ranks share ONE GPU to rehearse the N > 1 code path
-    backend = os.environ.get("GSR_BENCH_BACKEND", "nccl")
+    backend = os.environ.get("GSR_BENCH_BACKEND", "gloo" if args.dry_run else "nccl")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC for RCCL; must be set before the first HIP call
-    if backend != "nccl":
-        local_rank = local_rank % max(1, torch.cuda.device_count())
-    dev = torch.device("cuda", local_rank)
-    torch.cuda.set_device(dev)  # before any collective: RCCL binds the communicator to the current device
+    if args.dry_run:
+        dev = torch.device("cpu")
+    else:
+        if backend != "nccl":
+            local_rank = local_rank % max(1, torch.cuda.device_count())
+        dev = torch.device("cuda", local_rank)
+        torch.cuda.set_device(dev)  # before any collective: RCCL binds the communicator to the current device
     if world > 1:
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
+    try:
+        run_rank(args, rank, world, dev)
+    finally:
+        if world > 1:
+            dist.destroy_process_group()
 
-    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer, _C
-    _C.lib()  # fail loudly if the HIP library is missing
 
+def run_rank(args, rank, world, dev):
+    import view_parallel
     P, W, H, D, mu = gsr_scene.CONFIGS[args.config]
-    scene = gsr_scene.make_scene(P, mu, D, seed=0)          # replicated parameters
-    cam = gsr_scene.ring_camera(W, H, k=rank, n=max(world, 8)) if world > 1 else gsr_scene.make_camera(W, H)
-    M = scene.shs.shape[1]
-    to = lambda t: t.to(dev)
-    params = dict(means3D=to(scene.means3D).requires_grad_(True), shs=to(scene.shs).requires_grad_(True),
-                  opacities=to(scene.opacities).requires_grad_(True), scales=to(scene.scales).requires_grad_(True),
-                  rotations=to(scene.rotations).requires_grad_(True))
-    settings = GaussianRasterizationSettings(
-        image_height=H, image_width=W, tanfovx=cam.tanfovx, tanfovy=cam.tanfovy, bg=to(scene.bg), scale_modifier=1.0,
-        viewmatrix=to(cam.world_view_transform), projmatrix=to(cam.full_proj_transform), sh_degree=D,
-        campos=to(cam.camera_center), prefiltered=False, debug=False)
-    rasterizer = GaussianRasterizer(settings)
-    g = torch.Generator().manual_seed(1 + rank)
-    dpix = to(torch.randn(3, H, W, generator=g))
-    state = {}
-    bucket = None
-    compact = world > 1 and args.sh_exchange == "compact"
-    if world > 1:
-        import view_parallel
-        # one flat RCCL all-reduce: all 59 floats/Gaussian, or the 11 non-SH ones when SH goes the compact way
-        bucket = view_parallel.GradientBucket([v for k, v in params.items() if not (compact and k == "shs")])
+    M = (D + 1) ** 2
+    sync = (lambda: None) if args.dry_run else torch.cuda.synchronize
 
-    def step():
-        for p in params.values():
-            p.grad = None
-        means2D = torch.zeros_like(params["means3D"], requires_grad=True)  # gaussian_renderer/__init__.py:37
-        color, radii = rasterizer(means3D=params["means3D"], means2D=means2D, **{k: v for k, v in params.items() if k != "means3D"})
-        if compact:
-            with view_parallel.skip_sh_gradient() as side:
-                color.backward(dpix)
-            ex = view_parallel.ShExchange(settings.campos, side.dL_dRGB)     # async all-gather: 12 B per Gaussian per view
-            work = bucket.all_reduce(async_op=True)                          # the other 11 floats per Gaussian
-            params["shs"].grad = ex.finish(params["means3D"], D, M)          # rebuild kernel overlaps the all-reduce
-            if work is not None:
-                work.wait()
-        else:
-            color.backward(dpix)
-            if world > 1:  # view-parallel: sum the 59 floats/Gaussian of parameter gradients over ranks
-                bucket.all_reduce()
-        state["color"], state["radii"] = color, radii
+    def barrier():
+        sync()
+        if world > 1:
+            dist.barrier()
 
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    # Timed region: HIP events only around the dominant kernel (every event record drains the queue for
-    # ~5 us; bracketing all nine stages costs ~80 us per step, 4 % of it).  The full per-kernel table
-    # comes from a second, untimed pass below.
-    _C.profile_begin(only=DOMINANT_STAGE)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    dom_times = [ms for name, ms in _C.profile_end(capacity=4 * max(args.steps, 1)) if name == DOMINANT_STAGE]
-    table_steps = max(3, min(args.steps, 10))
-    _C.profile_begin()
-    for _ in range(table_steps):
-        step()
-    torch.cuda.synchronize()
-    ktimes = _C.profile_end(capacity=64 * table_steps)
-    if world > 1:
-        dist.barrier()
-    if world > 1:
-        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+    if args.dry_run:
+        # plumbing rehearsal: the exchange of one step on synthetic per-part buffers, nothing else
+        ex = {m: view_parallel.GradientExchange(P, M, dev, sh_mode=m, parts=args.parts) for m in ("compact", "allreduce")}
+        campos = torch.zeros(3)
 
-    if rank == 0:
-        # workload statistics for the algorithmic byte counts
-        radii = state["radii"]
-        V = int((radii > 0).sum().item())
-        N, T = W * H, ((W + 15) // 16) * ((H + 15) // 16)
-        # R and R' (instances actually staged by the forward blend) from the state buffers
-        cap = {}
-        orig = _C.rasterize_gaussians
+        def make_step(mode):
+            e = ex[mode]
 
-        def spy(*a):
-            r = orig(*a)
-            cap["R"], cap["img"] = r[0], r[5]
-            return r
-        _C.rasterize_gaussians = spy
-        with torch.no_grad():
-            rasterizer(means3D=params["means3D"], means2D=torch.zeros_like(params["means3D"]),
-                       **{k: v for k, v in params.items() if k != "means3D"})
-        _C.rasterize_gaussians = orig
-        R = int(cap["R"])
-        il = _C.image_layout(W, H)
-        tmc = cap["img"][il.tile_max_contrib:il.tile_max_contrib + 4 * T].view(torch.int32)
-        rng = cap["img"][il.ranges:il.ranges + 8 * T].view(torch.int32).view(T, 2)
-        # forward stages whole 256-batches until every pixel of the tile is done
-        staged = torch.minimum(((tmc + 256) // 256) * 256, rng[:, 1] - rng[:, 0])
-        Rp = int(staged.clamp(min=0).sum().item())
-        fwd_b, bwd_b = algorithmic_bytes(P, V, R, Rp, N, T, M)
-        per_kernel = {}
-        for name, ms in ktimes:
-            per_kernel.setdefault(name, []).append(ms)
-        kern = {}
-        allb = dict(fwd_b, **bwd_b)
-        for name, v in per_kernel.items():
-            avg = sum(v) / len(v)
-            kern[name] = dict(ms=round(avg, 4), launches=len(v), algorithmic_bytes=allb.get(name),
-                              GBps=round(allb[name] / (avg * 1e-3) / 1e9, 1) if allb.get(name) and avg > 0 else None)
-        step_bytes = sum(fwd_b.values()) + sum(bwd_b.values())
-        ms_per_step = elapsed / args.steps * 1e3
-        dom = max(kern, key=lambda k: kern[k]["ms"]) if kern else None
-        roofline = None
-        if dom:
-            if dom == DOMINANT_STAGE and dom_times:   # its launches inside the timed region
-                avg = sum(dom_times) / len(dom_times)
-                kern[dom].update(ms=round(avg, 4), launches=len(dom_times), measured_in="timed region",
-                                 GBps=round(allb[dom] / (avg * 1e-3) / 1e9, 1) if allb.get(dom) and avg > 0 else None)
-            a = kern[dom]["GBps"] or 0.0
-            roofline = dict(kernel=dom, bound="hbm", achieved=a, peak=HBM_PEAK_GBS, unit="GB/s",
-                            frac=round(a / HBM_PEAK_GBS, 4), traffic=pmc_traffic(dom, args.config),
-                            valu_issue_frac=pmc_valu_issue(dom, args.config),
-                            note="this kernel is VALU-issue-bound (PMC: SQ_ACTIVE_INST_VALU ~ 100 % of its duration), "
-                                 "so its HBM fraction is small by construction; see 'kernels' for the streaming stages",
-                            avg_launch_ms=kern[dom]["ms"], algorithmic_bytes_per_launch=kern[dom]["algorithmic_bytes"],
-                            step_algorithmic_bytes=step_bytes,
-                            step_GBps=round(step_bytes / (ms_per_step * 1e-3) / 1e9, 1),
-                            step_frac=round(step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
-        out = dict(metric="train iters/sec (fwd+bwd rasterize) @1980x1080, 1M Gaussians", value=round(world * args.steps / elapsed, 3),
-                   unit="it/s", n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(ms_per_step, 4),
-                   higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
-                   config=dict(workload=f"{args.config}: {P} Gaussians, SH deg {D}, {W}x{H}, mu={mu}, seed 0",
-                               P=P, V=V, R=R, R_staged_fwd=Rp, views_per_step=world,
-                               parallelism=(f"view-parallel x{world}, SH gradient exchange: {args.sh_exchange}"
-                                            if world > 1 else "single view")),
-                   roofline=roofline, kernels=kern,
-                   kernels_note=f"per-kernel ms: HIP events on the launch stream; '{DOMINANT_STAGE}' over the timed region, the "
-                                f"others over {table_steps} extra untimed steps (bracketing every stage inside the timed region "
-                                "would add ~80 us of event drains per step)")
-        if world == 1 and not args.no_extras:
-            out["loss_l1_ssim"] = bench_loss(state["color"].detach(), dev)
-            if not args.no_train_step:
+            def step():
+                e.begin_step()
+                for k in range(len(e.ranges)):
+                    e.bucket[k].fill_(float(rank + 1))
+                    e.submit(k, campos)
+                e.finish(None, D, rebuild_sh=False)
+            return step
+        steps = {m: make_step(m) for m in ex}
+        settings = None
+    else:
+        from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer, _C
+        _C.lib()  # fail loudly if the HIP library is missing
+        scene = gsr_scene.make_scene(P, mu, D, seed=0)          # replicated parameters
+        cam = gsr_scene.ring_camera(W, H, k=rank, n=max(world, 8)) if world > 1 else gsr_scene.make_camera(W, H)
+        M = scene.shs.shape[1]
+        to = lambda t: t.to(dev)
+        params = dict(means3D=to(scene.means3D).requires_grad_(True), shs=to(scene.shs).requires_grad_(True),
+                      opacities=to(scene.opacities).requires_grad_(True), scales=to(scene.scales).requires_grad_(True),
+                      rotations=to(scene.rotations).requires_grad_(True))
+        settings = GaussianRasterizationSettings(
+            image_height=H, image_width=W, tanfovx=cam.tanfovx, tanfovy=cam.tanfovy, bg=to(scene.bg), scale_modifier=1.0,
+            viewmatrix=to(cam.world_view_transform), projmatrix=to(cam.full_proj_transform), sh_degree=D,
+            campos=to(cam.camera_center), prefiltered=False, debug=False)
+        rasterizer = GaussianRasterizer(settings)
+        g = torch.Generator().manual_seed(1 + rank)
+        dpix = to(torch.randn(3, H, W, generator=g))
+        state = {}
+        ex = {m: view_parallel.GradientExchange(P, M, dev, sh_mode=m, parts=args.parts) for m in ("compact", "allreduce")} if world > 1 else {}
+
+        def make_step(mode):
+            def step():
                 for p in params.values():
                     p.grad = None
-                out["train_iteration"] = bench_train_step(scene, settings, D, dev)
-        if world == 1 and not args.no_cpu_baseline:
-            import numpy as np
-            cb, o = cpu_baseline(scene, cam, D)
-            out["cpu_baseline"] = cb
-            okm = (o["fragile"] == 0).reshape(H, W)
-            diff = np.abs(state["color"].detach().cpu().numpy() - o["color"])
-            out["image_L1_vs_oracle"] = float(diff.mean())
-            out["image_maxabs_vs_oracle_nonfragile"] = float(diff[:, okm].max())
-        print(json.dumps(out))
+                means2D = torch.zeros_like(params["means3D"], requires_grad=True)  # gaussian_renderer/__init__.py:37
+                if world > 1:
+                    # view-parallel: this rank's view; the backward exchanges the 59 floats/Gaussian of parameter
+                    # gradients part by part (view_parallel.GradientExchange) and returns their sum over the ranks
+                    color, radii = view_parallel.rasterize_view_parallel(params["means3D"], means2D, params["shs"], params["opacities"],
+                                                                         params["scales"], params["rotations"], settings, ex[mode])
+                else:
+                    color, radii = rasterizer(means3D=params["means3D"], means2D=means2D, **{k: v for k, v in params.items() if k != "means3D"})
+                color.backward(dpix)
+                state["color"], state["radii"] = color, radii
+            return step
+        steps = {m: make_step(m) for m in ("compact", "allreduce")}
+
+    def timed(step, nsteps, only=None):
+        """K steps between barriers; per-step times from one event per step boundary (K + 1 records)."""
+        barrier()
+        if not args.dry_run and only is not None:
+            _C.profile_begin(only=only)
+        marks = []
+
+        def mark():
+            if args.dry_run:
+                marks.append(time.perf_counter())
+            else:
+                e = torch.cuda.Event(enable_timing=True)
+                e.record()
+                marks.append(e)
+        t0 = time.perf_counter()
+        mark()
+        for _ in range(nsteps):
+            step()
+            mark()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        if args.dry_run:
+            per = [(b - a) * 1e3 for a, b in zip(marks[:-1], marks[1:])]
+        else:
+            per = [a.elapsed_time(b) for a, b in zip(marks[:-1], marks[1:])]
+        if world > 1:
+            tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            elapsed = float(tmax.item())
+        return elapsed, per
+
+    mode = args.sh_exchange
+    step = steps[mode]
+    for _ in range(args.warmup):
+        step()
+    # Timed region: HIP events only around the dominant kernel (every event record drains the queue for
+    # ~5 us; bracketing all stages costs ~80 us per step, 4 % of it) plus one event per step boundary.  The full
+    # per-kernel table comes from a second, untimed pass below.
+    elapsed, per_step = timed(step, args.steps, only=DOMINANT_STAGE)
+    dom_times, ktimes, table_steps = [], [], 0
+    if not args.dry_run:
+        dom_times = [ms for name, ms in _C.profile_end(capacity=4 * max(args.steps, 1)) if name == DOMINANT_STAGE]
+        table_steps = max(3, min(args.steps, 10))
+        _C.profile_begin()
+        for _ in range(table_steps):
+            step()
+        torch.cuda.synchronize()
+        ktimes = _C.profile_end(capacity=64 * table_steps)
+    alt = None
     if world > 1:
-        dist.destroy_process_group()
+        other = "allreduce" if mode == "compact" else "compact"
+        for _ in range(max(1, args.warmup)):
+            steps[other]()
+        e2, per2 = timed(steps[other], args.steps)
+        alt = dict(mode=other, value=round(world * args.steps / e2, 3), ms_per_step=round(e2 / args.steps * 1e3, 4), step_ms=step_stats(per2))
+
+    if rank != 0:
+        return
+    ms_per_step = elapsed / args.steps * 1e3
+    out = dict(metric="train iters/sec (fwd+bwd rasterize) @1980x1080, 1M Gaussians", value=round(world * args.steps / elapsed, 3),
+               unit="it/s", n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(ms_per_step, 4),
+               higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
+               step_ms=step_stats(per_step))
+    if alt is not None:
+        out["alt_exchange"] = alt
+    parallelism = (f"view-parallel x{world}, one view per rank, SH gradient exchange: {mode}, backward in {args.parts} parts"
+                   if world > 1 else "single view")
+    if args.dry_run:
+        out.update(data="dry-run: process-group plumbing and gradient exchange only, NO rasterizer (not a measurement)",
+                   config=dict(workload=f"{args.config}: exchange buffers of {P} Gaussians", P=P, views_per_step=world, parallelism=parallelism))
+        print(json.dumps(out), flush=True)
+        return
+
+    # workload statistics for the algorithmic byte counts
+    radii = state["radii"]
+    V = int((radii > 0).sum().item())
+    N, T = W * H, ((W + 15) // 16) * ((H + 15) // 16)
+    # R and R' (instances actually staged by the forward blend) from the state buffers
+    cap = {}
+    orig = _C.rasterize_gaussians
+
+    def spy(*a):
+        r = orig(*a)
+        cap["R"], cap["img"] = r[0], r[5]
+        return r
+    _C.rasterize_gaussians = spy
+    with torch.no_grad():
+        rasterizer(means3D=params["means3D"], means2D=torch.zeros_like(params["means3D"]),
+                   **{k: v for k, v in params.items() if k != "means3D"})
+    _C.rasterize_gaussians = orig
+    R = int(cap["R"])
+    il = _C.image_layout(W, H)
+    tmc = cap["img"][il.tile_max_contrib:il.tile_max_contrib + 4 * T].view(torch.int32)
+    rng = cap["img"][il.ranges:il.ranges + 8 * T].view(torch.int32).view(T, 2)
+    # forward stages whole 256-batches until every pixel of the tile is done
+    staged = torch.minimum(((tmc + 256) // 256) * 256, rng[:, 1] - rng[:, 0])
+    Rp = int(staged.clamp(min=0).sum().item())
+    fwd_b, bwd_b = algorithmic_bytes(P, V, R, Rp, N, T, M)
+    per_kernel = {}
+    for name, ms in ktimes:
+        per_kernel.setdefault(name, []).append(ms)
+    kern = {}
+    allb = dict(fwd_b, **bwd_b)
+    for name, v in per_kernel.items():
+        avg = sum(v) / len(v)
+        kern[name] = dict(ms=round(avg, 4), launches=len(v), algorithmic_bytes=allb.get(name),
+                          GBps=round(allb[name] / (avg * 1e-3) / 1e9, 1) if allb.get(name) and avg > 0 else None,
+                          hbm_frac=round(allb[name] / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 3) if allb.get(name) and avg > 0 else None)
+    step_bytes = sum(fwd_b.values()) + sum(bwd_b.values())
+    dom = max(kern, key=lambda k: kern[k]["ms"]) if kern else None
+    roofline = None
+    if dom:
+        if dom == DOMINANT_STAGE and dom_times:   # its launches inside the timed region
+            avg = sum(dom_times) / len(dom_times)
+            kern[dom].update(ms=round(avg, 4), launches=len(dom_times), measured_in="timed region",
+                             GBps=round(allb[dom] / (avg * 1e-3) / 1e9, 1) if allb.get(dom) and avg > 0 else None)
+        a = kern[dom]["GBps"] or 0.0
+        roofline = dict(kernel=dom, bound="hbm", achieved=a, peak=HBM_PEAK_GBS, unit="GB/s",
+                        frac=round(a / HBM_PEAK_GBS, 4), traffic=pmc_traffic(dom, args.config),
+                        valu_issue=valu_issue_fraction(dom, args.config, kern[dom]["ms"]),
+                        note="this kernel is bound by VALU issue, not by HBM (see valu_issue: share of the 1024 SIMDs' issue "
+                             "cycles its instructions occupy), so its HBM fraction is small by construction; 'kernels' "
+                             "lists the streaming stages with their own HBM fractions",
+                        avg_launch_ms=kern[dom]["ms"], algorithmic_bytes_per_launch=kern[dom]["algorithmic_bytes"],
+                        step_algorithmic_bytes=step_bytes,
+                        step_GBps=round(step_bytes / (ms_per_step * 1e-3) / 1e9, 1),
+                        step_frac=round(step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
+    out.update(config=dict(workload=f"{args.config}: {P} Gaussians, SH deg {D}, {W}x{H}, mu={mu}, seed 0",
+                           P=P, V=V, R=R, R_staged_fwd=Rp, views_per_step=world, parallelism=parallelism),
+               roofline=roofline, kernels=kern,
+               kernels_note=f"per-kernel ms: HIP events on the launch stream; '{DOMINANT_STAGE}' over the timed region, the "
+                            f"others over {table_steps} extra untimed steps (bracketing every stage inside the timed region "
+                            "would add ~80 us of event drains per step)")
+    if world == 1 and not args.no_extras:
+        out["loss_l1_ssim"] = bench_loss(state["color"].detach(), dev)
+        if not args.no_train_step:
+            for p in params.values():
+                p.grad = None
+            out["train_iteration"] = bench_train_step(scene, settings, D, dev)
+    if world == 1 and not args.no_cpu_baseline:
+        import numpy as np
+        cb, o = cpu_baseline(scene, cam, D)
+        out["cpu_baseline"] = cb
+        out["cpu_baseline_torch"] = cpu_baseline_torch()
+        out["parity_vs_oracle"] = parity_figures(o, state["color"], params, dpix, rasterizer, H, W)
+    print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -5,6 +5,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <atomic>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -43,78 +44,99 @@ int gsr_stage_done(hipStream_t s, int debug, const char* stage)
 }
 
 extern "C" const char* gsr_last_error(void) { return g_err; }
-extern "C" const char* gsr_version(void) { return "gsr-hip gfx950 r1"; }
+extern "C" const char* gsr_version(void) { return "gsr-hip gfx950 r2"; }
 
 // ---- per-kernel event profiling ----------------------------------------------------------------
-// Events come from a pool that only grows, so recording inside a timed region costs two
-// hipEventRecord per stage and no allocation after the first step.
+// One recorder per stream that asked for it (gsr_profile_begin(stream)).  A stage looks its stream up; with no
+// recorder active anywhere that is one relaxed atomic load.  Events come from a pool that only grows, so
+// recording inside a timed region costs two hipEventRecord per stage and no allocation after the first step.
+// Nothing here is keyed by thread: PyTorch runs the backward on its own autograd thread, one per device, and
+// each of them is told apart by the stream it passes.
 struct ProfEntry { const char* name; hipEvent_t a, b; };
-// Process-global (PyTorch runs backward on its own autograd thread), guarded by a mutex.
+struct ProfRecorder {
+	hipStream_t stream;
+	bool on = false, open = false;
+	std::vector<ProfEntry> ev;
+	size_t used = 0;
+	char only[64] = "";  // when non-empty: record this stage only (every hipEventRecord drains the queue ~5 us)
+};
 static std::mutex g_prof_mu;
-static bool g_prof_on = false;
-static std::vector<ProfEntry>* g_prof = nullptr;
-static size_t g_prof_used = 0;
-static char g_prof_only[64] = "";   // when non-empty: record this stage only (every hipEventRecord drains the queue ~5 us)
-static bool g_prof_open = false;
+static std::vector<ProfRecorder*> g_prof;  // guarded by g_prof_mu; recorders are kept for reuse of their events
+static std::atomic<int> g_prof_active{0};
+
+static ProfRecorder* prof_find(hipStream_t s, bool create)
+{
+	for (ProfRecorder* r : g_prof)
+		if (r->stream == s) return r;
+	if (!create) return nullptr;
+	ProfRecorder* r = new ProfRecorder();
+	r->stream = s;
+	g_prof.push_back(r);
+	return r;
+}
 
 void gsr_prof_mark_begin(hipStream_t s, const char* name)
 {
+	if (g_prof_active.load(std::memory_order_relaxed) == 0) return;
 	std::lock_guard<std::mutex> lk(g_prof_mu);
-	g_prof_open = false;
-	if (!g_prof_on || (g_prof_only[0] && strcmp(g_prof_only, name) != 0)) return;
-	g_prof_open = true;
-	if (g_prof_used == g_prof->size()) {
+	ProfRecorder* r = prof_find(s, false);
+	if (!r || !r->on) return;
+	r->open = false;
+	if (r->only[0] && strcmp(r->only, name) != 0) return;
+	r->open = true;
+	if (r->used == r->ev.size()) {
 		ProfEntry e;
 		e.name = name;
 		(void)hipEventCreate(&e.a);
 		(void)hipEventCreate(&e.b);
-		g_prof->push_back(e);
+		r->ev.push_back(e);
 	}
-	ProfEntry& e = (*g_prof)[g_prof_used++];
+	ProfEntry& e = r->ev[r->used++];
 	e.name = name;
 	(void)hipEventRecord(e.a, s);
 }
 
 void gsr_prof_mark_end(hipStream_t s)
 {
+	if (g_prof_active.load(std::memory_order_relaxed) == 0) return;
 	std::lock_guard<std::mutex> lk(g_prof_mu);
-	if (!g_prof_on || !g_prof_open || g_prof_used == 0) return;
-	g_prof_open = false;
-	(void)hipEventRecord((*g_prof)[g_prof_used - 1].b, s);
+	ProfRecorder* r = prof_find(s, false);
+	if (!r || !r->on || !r->open || r->used == 0) return;
+	r->open = false;
+	(void)hipEventRecord(r->ev[r->used - 1].b, s);
 }
 
-extern "C" int gsr_profile_begin(void)
+extern "C" int gsr_profile_begin_only(void* stream, const char* stage)
 {
 	std::lock_guard<std::mutex> lk(g_prof_mu);
-	if (!g_prof) g_prof = new std::vector<ProfEntry>();
-	g_prof_used = 0;
-	g_prof_on = true;
-	g_prof_only[0] = 0;
+	ProfRecorder* r = prof_find((hipStream_t)stream, true);
+	if (!r->on) g_prof_active.fetch_add(1);
+	r->on = true;
+	r->open = false;
+	r->used = 0;
+	r->only[0] = 0;
+	if (stage) { strncpy(r->only, stage, sizeof r->only - 1); r->only[sizeof r->only - 1] = 0; }
 	return GSR_OK;
 }
 
-extern "C" int gsr_profile_begin_only(const char* stage)
-{
-	const int rc = gsr_profile_begin();
-	std::lock_guard<std::mutex> lk(g_prof_mu);
-	if (stage) { strncpy(g_prof_only, stage, sizeof g_prof_only - 1); g_prof_only[sizeof g_prof_only - 1] = 0; }
-	return rc;
-}
+extern "C" int gsr_profile_begin(void* stream) { return gsr_profile_begin_only(stream, nullptr); }
 
-extern "C" int gsr_profile_end(gsr_kernel_time* out, int capacity)
+extern "C" int gsr_profile_end(void* stream, gsr_kernel_time* out, int capacity)
 {
 	std::lock_guard<std::mutex> lk(g_prof_mu);
-	if (!g_prof_on) return 0;
-	g_prof_on = false;
+	ProfRecorder* r = prof_find((hipStream_t)stream, false);
+	if (!r || !r->on) return 0;
+	r->on = false;
+	g_prof_active.fetch_sub(1);
 	int n = 0;
-	for (size_t k = 0; k < g_prof_used; k++) {
-		ProfEntry& e = (*g_prof)[k];
+	for (size_t k = 0; k < r->used; k++) {
+		ProfEntry& e = r->ev[k];
 		(void)hipEventSynchronize(e.b);
 		float ms = 0.f;
 		(void)hipEventElapsedTime(&ms, e.a, e.b);
-		if (n < capacity) { out[n].name = e.name; out[n].ms = ms; n++; }
+		if (out && n < capacity) { out[n].name = e.name; out[n].ms = ms; n++; }
 	}
-	g_prof_used = 0;
+	r->used = 0;
 	return n;
 }
 
@@ -131,6 +153,8 @@ extern "C" int gsr_geometry_layout_of(int P, gsr_geometry_layout* o)
 	o->perm = off;           off = gsr_align_up(off + n * 4);
 	o->perm_alt = off;       off = gsr_align_up(off + n * 4);
 	o->tiles_touched = off;  off = gsr_align_up(off + n * 4);
+	o->rect = off;           off = gsr_align_up(off + n * 8);
+	o->slot_base = off;      off = gsr_align_up(off + n * 4);
 	o->clamped = off;        off = gsr_align_up(off + n);
 	o->status = off;         off = gsr_align_up(off + GSR_STATUS_WORDS * 4);
 	o->scan_temp = off;      off = gsr_align_up(off + 2 * gsr_align_up(nb * 4));
@@ -148,6 +172,7 @@ extern "C" int gsr_image_layout_of(int W, int H, gsr_image_layout* o)
 	o->n_contrib = off;        off = gsr_align_up(off + N * 4);
 	o->ranges = off;           off = gsr_align_up(off + T * 8);
 	o->tile_max_contrib = off; off = gsr_align_up(off + T * 4);
+	o->tile_order = off;       off = gsr_align_up(off + T * 4);
 	o->total = off;
 	return GSR_OK;
 }
@@ -202,6 +227,8 @@ GsrGeometry gsr_geometry_view(void* blob, int P)
 	g.perm = (uint32_t*)(b + l.perm);
 	g.perm_alt = (uint32_t*)(b + l.perm_alt);
 	g.tiles_touched = (uint32_t*)(b + l.tiles_touched);
+	g.rect = (uint2*)(b + l.rect);
+	g.slot_base = (uint32_t*)(b + l.slot_base);
 	g.clamped = (uint8_t*)(b + l.clamped);
 	g.status = (uint32_t*)(b + l.status);
 	g.block_sums = (uint32_t*)(b + l.scan_temp);
@@ -220,6 +247,7 @@ GsrImage gsr_image_view(void* blob, int W, int H)
 	im.n_contrib = (uint32_t*)(b + l.n_contrib);
 	im.ranges = (uint2*)(b + l.ranges);
 	im.tile_max_contrib = (uint32_t*)(b + l.tile_max_contrib);
+	im.tile_order = (uint32_t*)(b + l.tile_order);
 	return im;
 }
 
@@ -267,7 +295,7 @@ static int gsr_forward_preprocess_impl(int P, int D, int M, int width, int heigh
 	*num_rendered_host = 0;
 	if (P < 0 || width <= 0 || height <= 0) return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "bad P / image size");
 	if (P == 0) return GSR_OK;  // rasterize_points.cu:94: nothing is launched for an empty scene
-	if (!means3D || !opacities || !viewmatrix || !projmatrix || !radii || !geometry)
+	if (!means3D || !opacities || !viewmatrix || !projmatrix || !geometry)  // radii is optional (rasterizer.h:52)
 		return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "gsr_forward_preprocess: required pointer is NULL");
 	if (!colors_precomp && !shs)  // rasterizer_impl.cu:281-284
 		return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "For non-RGB, provide precomputed Gaussian colors!");
@@ -415,74 +443,106 @@ extern "C" int gsr_forward_render(int P, int64_t R, int width, int height, const
 }
 
 // ---- backward ----------------------------------------------------------------------------------
-static int gsr_backward_impl(int P, int D, int M, int64_t R, int width, int height, const float* background,
-                             const float* means3D, const float* shs, const float* shs_rest, int leaf,
-                             const float* colors_precomp, const float* scales, float scale_modifier,
-                             const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
-                             const float* projmatrix, const float* cam_pos, float tan_fovx, float tan_fovy,
-                             const int* radii, void* geometry, void* binning, void* image, void* scratch,
-                             const float* dL_dpix, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity,
-                             float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dsh_rest,
-                             float* dL_dscale, float* dL_drot, void* stream, int debug)
+static int gsr_backward_check(const gsr_backward_args& a, const char* who)
 {
-	g_err[0] = 0;
-	hipStream_t s = (hipStream_t)stream;
-	if (P < 0 || R < 0 || width <= 0 || height <= 0) return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "bad sizes");
-	if (P == 0) return GSR_OK;
-	if (!background || !means3D || !viewmatrix || !projmatrix || !radii || !geometry || !image || !dL_dpix ||
-	    !dL_dmean2D || !dL_dopacity || !dL_dmean3D || !dL_dscale || !dL_drot || (R > 0 && (!binning || !scratch)))
+	if (a.P < 0 || a.num_rendered < 0 || a.width <= 0 || a.height <= 0) return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "%s: bad sizes", who);
+	if (a.P == 0) return GSR_OK;
+	if (!a.background || !a.means3D || !a.viewmatrix || !a.projmatrix || !a.geometry || !a.image || !a.dL_dpix ||
+	    !a.dL_dmean2D || !a.dL_dopacity || !a.dL_dmean3D || !a.dL_dscale || !a.dL_drot || (a.num_rendered > 0 && (!a.binning || !a.scratch)))
 		return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "gsr_backward: required pointer is NULL");
 	// dL_dconic is an intermediate; dL_dcolor / dL_dcov3D are only results when the colours / covariances were
 	// inputs (or, dL_dcolor, in view-parallel mode): NULL = not written
-	if (!leaf && ((colors_precomp && !dL_dcolor) || (cov3D_precomp && !dL_dcov3D) || (shs && !dL_dsh && !dL_dcolor)))
+	if (!a.leaf && ((a.colors_precomp && !a.dL_dcolor) || (a.cov3D_precomp && !a.dL_dcov3D) || (a.shs && !a.dL_dsh && !a.dL_dcolor)))
 		return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "gsr_backward: the gradient of a provided input is NULL");
-	if (leaf) {
-		if (!shs || !scales || !rotations || (M > 1 && !shs_rest))
+	if (a.leaf) {
+		if (!a.shs || !a.scales || !a.rotations || (a.M > 1 && !a.shs_rest))
 			return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "gsr_backward_leaf: a leaf tensor is NULL");
-		if (M > 16) return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "gsr_backward_leaf: at most 16 SH coefficients (degree 3), M = %d", M);
-		if ((dL_dsh == nullptr) != (dL_dsh_rest == nullptr) && M > 1)
+		if (a.M > 16) return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "gsr_backward_leaf: at most 16 SH coefficients (degree 3), M = %d", a.M);
+		if ((a.dL_dsh == nullptr) != (a.dL_dsh_rest == nullptr) && a.M > 1)
 			return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "gsr_backward_leaf: pass both feature gradients or neither");
-		if (!dL_dsh && !dL_dcolor)
+		if (!a.dL_dsh && !a.dL_dcolor)
 			return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "gsr_backward_leaf: without feature gradients dL_dRGB is required");
 	}
-	if (!aligned16(geometry) || !aligned16(image) || !aligned16(binning) || !aligned16(scratch))
+	if (a.stat_max_radii2D && !a.radii)
+		return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "gsr_backward: stat_max_radii2D needs radii");
+	if (!aligned16(a.geometry) || !aligned16(a.image) || !aligned16(a.binning) || !aligned16(a.scratch))
 		return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "state buffers must be 16-byte aligned");
+	return GSR_OK;
+}
 
-	GsrGeometry g = gsr_geometry_view(geometry, P);
-	GsrImage im = gsr_image_view(image, width, height);
-	GsrGradSlot* slots = (GsrGradSlot*)scratch;
-	// Validity bytes of the slots: the tile sort's dead ping-pong buffer, cleared at the end of the forward.
-	// Which slots get written depends on the forward alone (not on dL_dpix), so a second backward over the
-	// same forward state (retain_graph) finds exactly the bytes it would set itself.
-	uint8_t* slot_valid = nullptr;
+// Validity bytes of the gradient slots: the tile sort's dead ping-pong buffer, cleared at the end of the forward.
+// Which slots get written depends on the forward alone (not on dL_dpix), so a second backward over the
+// same forward state (retain_graph) finds exactly the bytes it would set itself.
+static uint8_t* gsr_slot_valid_of(const gsr_backward_args& a)
+{
+	if (a.num_rendered <= 0) return nullptr;
+	return (uint8_t*)gsr_binning_view(a.binning, a.P, a.num_rendered, a.width, a.height).tile_keys_alt;
+}
+
+extern "C" int gsr_backward_blend(const gsr_backward_args* args)
+{
+	g_err[0] = 0;
+	if (!args) return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "gsr_backward_blend: args is NULL");
+	const gsr_backward_args& a = *args;
 	int rc;
-	if (R > 0) {
-		GsrBinning b = gsr_binning_view(binning, P, R, width, height);
-		slot_valid = (uint8_t*)b.tile_keys_alt;
-		{
-			GsrProfScope p(s, "render_backward");
-			gsr_launch_render_backward(width, height, im, b.point_list, g.splat, background, dL_dpix, slots, slot_valid, s);
-		}
-		if ((rc = gsr_stage_done(s, debug, "render_backward"))) return rc;
+	if ((rc = gsr_backward_check(a, "gsr_backward_blend"))) return rc;
+	if (a.P == 0 || a.num_rendered == 0) return GSR_OK;
+	hipStream_t s = (hipStream_t)a.stream;
+	GsrGeometry g = gsr_geometry_view(a.geometry, a.P);
+	GsrImage im = gsr_image_view(a.image, a.width, a.height);
+	GsrBinning b = gsr_binning_view(a.binning, a.P, a.num_rendered, a.width, a.height);
+	{
+		GsrProfScope p(s, "tile_order");
+		gsr_launch_tile_order(im, gsr_grid_x(a.width) * gsr_grid_y(a.height), s);
 	}
+	if ((rc = gsr_stage_done(s, a.debug, "tile_order"))) return rc;
+	{
+		GsrProfScope p(s, "render_backward");
+		gsr_launch_render_backward(a.width, a.height, im, b.point_list, g.splat, g.slot_base, a.background, a.dL_dpix,
+		                           (GsrGradSlot*)a.scratch, (uint8_t*)b.tile_keys_alt, s);
+	}
+	return gsr_stage_done(s, a.debug, "render_backward");
+}
 
+extern "C" int gsr_backward_gaussians(const gsr_backward_args* args, int first, int count, int out_row0)
+{
+	g_err[0] = 0;
+	if (!args) return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "gsr_backward_gaussians: args is NULL");
+	const gsr_backward_args& b = *args;
+	int rc;
+	if ((rc = gsr_backward_check(b, "gsr_backward_gaussians"))) return rc;
+	if (first < 0 || count < 0 || (int64_t)first + count > b.P || (first & 63) || (out_row0 != 0 && out_row0 != first))
+		return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "gsr_backward_gaussians: bad range [%d, %d + %d) of %d Gaussians (first must be a multiple "
+		                "of 64, out_row0 must be 0 or first)", first, first, count, b.P);
+	if (count == 0) return GSR_OK;
+	hipStream_t s = (hipStream_t)b.stream;
 	GsrGaussianBackwardArgs a = {};
-	a.leaf = leaf; a.shs_rest = shs_rest; a.dL_dsh_rest = dL_dsh_rest;
-	a.P = P; a.D = D; a.M = M; a.W = width; a.H = height;
-	a.means3D = means3D; a.shs = shs; a.colors_precomp = colors_precomp; a.scales = scales;
-	a.scale_modifier = scale_modifier; a.rotations = rotations; a.cov3D_precomp = cov3D_precomp;
-	a.viewmatrix = viewmatrix; a.projmatrix = projmatrix; a.cam_pos = cam_pos;
-	a.tan_fovx = tan_fovx; a.tan_fovy = tan_fovy;
-	a.focal_y = height / (2.0f * tan_fovy);
-	a.focal_x = width / (2.0f * tan_fovx);
-	a.radii = radii; a.g = g; a.slots = slots; a.slot_valid = slot_valid;
-	a.dL_dmean2D = dL_dmean2D; a.dL_dconic = dL_dconic; a.dL_dopacity = dL_dopacity; a.dL_dcolor = dL_dcolor;
-	a.dL_dmean3D = dL_dmean3D; a.dL_dcov3D = dL_dcov3D; a.dL_dsh = dL_dsh; a.dL_dscale = dL_dscale; a.dL_drot = dL_drot;
+	a.leaf = b.leaf; a.shs_rest = b.shs_rest; a.dL_dsh_rest = b.dL_dsh_rest;
+	a.P = b.P; a.D = b.D; a.M = b.M; a.W = b.width; a.H = b.height;
+	a.first = first; a.count = count; a.out_row0 = out_row0;
+	a.means3D = b.means3D; a.shs = b.shs; a.colors_precomp = b.colors_precomp; a.scales = b.scales;
+	a.scale_modifier = b.scale_modifier; a.rotations = b.rotations; a.cov3D_precomp = b.cov3D_precomp;
+	a.viewmatrix = b.viewmatrix; a.projmatrix = b.projmatrix; a.cam_pos = b.cam_pos;
+	a.tan_fovx = b.tan_fovx; a.tan_fovy = b.tan_fovy;
+	a.focal_y = b.height / (2.0f * b.tan_fovy);
+	a.focal_x = b.width / (2.0f * b.tan_fovx);
+	a.radii = b.radii; a.g = gsr_geometry_view(b.geometry, b.P);
+	a.slots = (const GsrGradSlot*)b.scratch; a.slot_valid = gsr_slot_valid_of(b);
+	a.dL_dmean2D = b.dL_dmean2D; a.dL_dconic = b.dL_dconic; a.dL_dopacity = b.dL_dopacity; a.dL_dcolor = b.dL_dcolor;
+	a.dL_dmean3D = b.dL_dmean3D; a.dL_dcov3D = b.dL_dcov3D; a.dL_dsh = b.dL_dsh; a.dL_dscale = b.dL_dscale; a.dL_drot = b.dL_drot;
+	a.stat_xyz_gradient_accum = b.stat_xyz_gradient_accum; a.stat_denom = b.stat_denom; a.stat_max_radii2D = b.stat_max_radii2D;
 	{
 		GsrProfScope p(s, "gaussian_backward");
 		gsr_launch_gaussian_backward(a, s);
 	}
-	return gsr_stage_done(s, debug, "gaussian_backward");
+	return gsr_stage_done(s, b.debug, "gaussian_backward");
+}
+
+static int gsr_backward_whole(const gsr_backward_args& a)
+{
+	int rc;
+	if ((rc = gsr_backward_blend(&a))) return rc;
+	return gsr_backward_gaussians(&a, 0, a.P, 0);
 }
 
 extern "C" int gsr_backward(int P, int D, int M, int64_t R, int width, int height, const float* background,
@@ -495,10 +555,16 @@ extern "C" int gsr_backward(int P, int D, int M, int64_t R, int width, int heigh
                             float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, void* stream,
                             int debug)
 {
-	return gsr_backward_impl(P, D, M, R, width, height, background, means3D, shs, nullptr, 0, colors_precomp, scales,
-	                         scale_modifier, rotations, cov3D_precomp, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy,
-	                         radii, geometry, binning, image, scratch, dL_dpix, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor,
-	                         dL_dmean3D, dL_dcov3D, dL_dsh, nullptr, dL_dscale, dL_drot, stream, debug);
+	gsr_backward_args a = {};
+	a.P = P; a.D = D; a.M = M; a.num_rendered = R; a.width = width; a.height = height; a.leaf = 0;
+	a.background = background; a.means3D = means3D; a.shs = shs; a.colors_precomp = colors_precomp; a.scales = scales;
+	a.scale_modifier = scale_modifier; a.rotations = rotations; a.cov3D_precomp = cov3D_precomp; a.viewmatrix = viewmatrix;
+	a.projmatrix = projmatrix; a.cam_pos = cam_pos; a.tan_fovx = tan_fovx; a.tan_fovy = tan_fovy; a.radii = radii;
+	a.geometry = geometry; a.binning = binning; a.image = image; a.scratch = scratch; a.dL_dpix = dL_dpix;
+	a.dL_dmean2D = dL_dmean2D; a.dL_dconic = dL_dconic; a.dL_dopacity = dL_dopacity; a.dL_dcolor = dL_dcolor;
+	a.dL_dmean3D = dL_dmean3D; a.dL_dcov3D = dL_dcov3D; a.dL_dsh = dL_dsh; a.dL_dscale = dL_dscale; a.dL_drot = dL_drot;
+	a.stream = stream; a.debug = debug;
+	return gsr_backward_whole(a);
 }
 
 extern "C" int gsr_backward_leaf(int P, int D, int M, int64_t R, int width, int height, const float* background,
@@ -510,11 +576,16 @@ extern "C" int gsr_backward_leaf(int P, int D, int M, int64_t R, int width, int 
                                  float* dL_dfeatures_dc, float* dL_dfeatures_rest, float* dL_dopacity_logits,
                                  float* dL_dlog_scales, float* dL_draw_rotations, float* dL_dRGB, void* stream, int debug)
 {
-	return gsr_backward_impl(P, D, M, R, width, height, background, xyz, features_dc, features_rest, 1, nullptr, log_scales,
-	                         scale_modifier, raw_rotations, nullptr, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, radii,
-	                         geometry, binning, image, scratch, dL_dpix, dL_dmean2D, nullptr, dL_dopacity_logits, dL_dRGB,
-	                         dL_dxyz, nullptr, dL_dfeatures_dc, dL_dfeatures_rest, dL_dlog_scales, dL_draw_rotations, stream,
-	                         debug);
+	gsr_backward_args a = {};
+	a.P = P; a.D = D; a.M = M; a.num_rendered = R; a.width = width; a.height = height; a.leaf = 1;
+	a.background = background; a.means3D = xyz; a.shs = features_dc; a.shs_rest = features_rest; a.scales = log_scales;
+	a.scale_modifier = scale_modifier; a.rotations = raw_rotations; a.viewmatrix = viewmatrix; a.projmatrix = projmatrix;
+	a.cam_pos = cam_pos; a.tan_fovx = tan_fovx; a.tan_fovy = tan_fovy; a.radii = radii;
+	a.geometry = geometry; a.binning = binning; a.image = image; a.scratch = scratch; a.dL_dpix = dL_dpix;
+	a.dL_dmean2D = dL_dmean2D; a.dL_dopacity = dL_dopacity_logits; a.dL_dcolor = dL_dRGB; a.dL_dmean3D = dL_dxyz;
+	a.dL_dsh = dL_dfeatures_dc; a.dL_dsh_rest = dL_dfeatures_rest; a.dL_dscale = dL_dlog_scales; a.dL_drot = dL_draw_rotations;
+	a.stream = stream; a.debug = debug;
+	return gsr_backward_whole(a);
 }
 
 extern "C" size_t gsr_loss_scratch_bytes(int C, int H, int W)

@@ -85,8 +85,7 @@ void gsr_launch_sorted_block_sums(GsrGeometry g, int P, hipStream_t s)
 
 // ---- key emission ----------------------------------------------------------------------------
 // Thread i handles the i-th Gaussian in depth order.  Its first slot is the workgroup prefix plus
-// an in-workgroup scan, written back into the splat record (the backward blend addresses its
-// per-(Gaussian,tile) gradient slots with it).  The 64 Gaussians of a wave own ONE contiguous run
+// an in-workgroup scan, kept per Gaussian in GsrGeometry::slot_base.  The 64 Gaussians of a wave own ONE contiguous run
 // of output positions, so the wave emits cooperatively: lane l writes positions l, l+64, ... of the
 // run and finds the owning Gaussian of a position by binary search over the wave's 64 start offsets
 // (LDS).  Every store instruction then writes 64 consecutive elements, whatever the rectangle
@@ -107,17 +106,18 @@ __global__ void __launch_bounds__(GSR_PREPROCESS_BLOCK) gsr_duplicate_keys_kerne
 	uint32_t idx = 0, tiles = 0, rmin = 0, w = 1;
 	if (i < P) {
 		idx = g.perm[i];
-		tiles = g.tiles_touched[idx];
+		const uint2 rc = g.rect[idx];  // 8-byte gather from a dense array (L2 / Infinity-Cache resident)
+		rmin = rc.x;
+		w = rc.y & 0xffffu;
+		tiles = w * (rc.y >> 16);      // = tiles_touched (0 for culled Gaussians)
+		if (!tiles) w = 1;
 	}
 	uint32_t total;
 	const uint32_t incl = gsr_block_incl_scan<GSR_PREPROCESS_BLOCK>(tiles, &total, lds) + g.sorted_block_sums[blockIdx.x];
 	const uint32_t off = incl - tiles;
-	if (tiles) {
-		GsrSplat* sp = g.splat + idx;
-		sp->slot_base = off;
-		rmin = sp->rect_min;
-		w = sp->rect_wh & 0xffffu;
-	}
+	// the backward blend addresses its per-(Gaussian,tile) gradient slots with this; a 4-byte scatter into a dense
+	// 4*P-byte array that the caches absorb (into the 48-byte splat records it cost 2x write amplification)
+	if (tiles) g.slot_base[idx] = off;
 	const uint32_t wave_first = __shfl(off, 0, 64);
 	const uint32_t wave_total = __shfl(incl, 63, 64) - wave_first;
 	s_start[wave][lane] = off - wave_first;
@@ -190,6 +190,43 @@ __global__ void __launch_bounds__(256) gsr_tile_ranges_kernel(const uint32_t* __
 		}
 		prevtile = currtile;
 	}
+}
+
+// ---- dispatch order of the backward blend ---------------------------------------------------------
+// One wave per tile, 4 waves per SIMD: ~2 waves of tiles per launch, so the last tiles to start decide when the
+// kernel ends.  Tiles are handed out in descending order of their work (instances the backward will stage =
+// min(range length, largest n_contrib of the tile)): longest-processing-time-first.  A counting sort on
+// work / 16 (1024 bins, saturating) by ONE workgroup; the order inside a bin is arbitrary (it only affects
+// scheduling: every tile's result is independent of when it runs).
+#define GSR_ORDER_BINS 1024
+__global__ void __launch_bounds__(1024) gsr_tile_order_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ tile_max_contrib,
+                                                              uint32_t ntiles, uint32_t* __restrict__ order)
+{
+	__shared__ uint32_t bin[GSR_ORDER_BINS];
+	__shared__ uint32_t wsum[1024 / 64];
+	bin[threadIdx.x] = 0;
+	__syncthreads();
+	for (uint32_t t = threadIdx.x; t < ntiles; t += 1024) {
+		const uint2 r = ranges[t];
+		const uint32_t work = min(r.y - r.x, tile_max_contrib[t]);
+		atomicAdd(&bin[GSR_ORDER_BINS - 1 - min(work >> 4, (uint32_t)GSR_ORDER_BINS - 1)], 1u);  // bin 0 = most work
+	}
+	__syncthreads();
+	const uint32_t c = bin[threadIdx.x];
+	uint32_t total;
+	const uint32_t incl = gsr_block_incl_scan<1024>(c, &total, wsum);
+	bin[threadIdx.x] = incl - c;  // first position of the bin
+	__syncthreads();
+	for (uint32_t t = threadIdx.x; t < ntiles; t += 1024) {
+		const uint2 r = ranges[t];
+		const uint32_t work = min(r.y - r.x, tile_max_contrib[t]);
+		order[atomicAdd(&bin[GSR_ORDER_BINS - 1 - min(work >> 4, (uint32_t)GSR_ORDER_BINS - 1)], 1u)] = t;
+	}
+}
+
+void gsr_launch_tile_order(GsrImage img, int ntiles, hipStream_t s)
+{
+	hipLaunchKernelGGL(gsr_tile_order_kernel, dim3(1), dim3(1024), 0, s, img.ranges, img.tile_max_contrib, (uint32_t)ntiles, img.tile_order);
 }
 
 void gsr_launch_tile_ranges(const uint32_t* tile_keys, int64_t R, uint2* ranges, int ntiles, uint32_t* valid, hipStream_t s)

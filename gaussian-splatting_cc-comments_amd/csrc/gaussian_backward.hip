@@ -171,13 +171,19 @@ template <bool LEAF>
 __global__ void __launch_bounds__(GSR_GB_THREADS) gsr_gaussian_backward_kernel(GsrGaussianBackwardArgs a, int sh_via_lds, int skip_dsh)
 {
 	__shared__ float4 s_sh[GSR_GB_THREADS / 64][64 * GSR_SH_ROW4];
-	const int idx = blockIdx.x * GSR_GB_THREADS + threadIdx.x;
+	// the launch covers the Gaussians [first, first + count): the whole scene, or one part of it when the caller
+	// pipelines the gradient exchange of a finished part under the kernel of the next (gsr_backward_gaussians)
+	const int idx = a.first + blockIdx.x * GSR_GB_THREADS + threadIdx.x;
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	const int M = a.M;
-	const bool in_range = idx < a.P;
-	const bool visible = in_range && a.radii[idx] > 0;
-	const int wave_first = blockIdx.x * GSR_GB_THREADS + wave * 64;
-	const int nrows = min(64, a.P - wave_first);  // Gaussians of this wave (<= 0: none)
+	const int end = a.first + a.count;
+	const bool in_range = idx < end;
+	uint32_t tiles = 0, base = 0;
+	if (in_range) tiles = a.g.tiles_touched[idx];
+	// radii > 0 <=> tiles_touched > 0 (forward.cu:300-301 zeroes both together)
+	const bool visible = in_range && (a.radii ? a.radii[idx] > 0 : tiles > 0);
+	const int wave_first = a.first + blockIdx.x * GSR_GB_THREADS + wave * 64;
+	const int nrows = min(64, end - wave_first);  // Gaussians of this wave (<= 0: none)
 
 	// ---- stage the wave's SH block (64 x 48 floats, contiguous in HBM) into LDS, coalesced ----
 	if (sh_via_lds && nrows > 0) {
@@ -189,11 +195,8 @@ __global__ void __launch_bounds__(GSR_GB_THREADS) gsr_gaussian_backward_kernel(G
 	float acc[GSR_NACC];
 #pragma unroll
 	for (int i = 0; i < GSR_NACC; i++) acc[i] = 0.f;
-	uint32_t tiles = 0, base = 0;
-	if (visible) {
-		tiles = a.g.tiles_touched[idx];
-		base = a.g.splat[idx].slot_base;
-	}
+	if (visible) base = a.g.slot_base[idx];
+	else tiles = 0;
 	if (tiles <= GSR_SLOT_COOP) {
 		// four slots per round: their validity bytes and records are all requested before the first add
 		// (one round trip of memory latency per four slots instead of two per slot); same addition order
@@ -237,7 +240,10 @@ __global__ void __launch_bounds__(GSR_GB_THREADS) gsr_gaussian_backward_kernel(G
 	float dcolor[3] = {acc[6], acc[7], acc[8]};
 	float dmean3D[3] = {0.f, 0.f, 0.f}, dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 	float dscale[3] = {0.f, 0.f, 0.f}, drot[4] = {0.f, 0.f, 0.f, 0.f};
-	float* dsh_global = (!LEAF && a.dL_dsh && in_range) ? a.dL_dsh + (size_t)idx * M * 3 : nullptr;
+	// gradient outputs are indexed relative to out_row0 (0, or `first` when each part has a buffer of its own)
+	const size_t orow = (size_t)(idx - a.out_row0);
+	const int out_wave_first = wave_first - a.out_row0;
+	float* dsh_global = (!LEAF && a.dL_dsh && in_range) ? a.dL_dsh + orow * M * 3 : nullptr;
 	float sh_local[48], dsh_local[48];  // LEAF without the LDS path: gathered rows / their gradient
 	float q_raw[4] = {0.f, 0.f, 0.f, 0.f}, q_den = 1.f;
 	float dRGB[3] = {0.f, 0.f, 0.f};  // dL/dcolor with the channels clamped by the forward zeroed
@@ -404,8 +410,8 @@ __global__ void __launch_bounds__(GSR_GB_THREADS) gsr_gaussian_backward_kernel(G
 		}
 		__builtin_amdgcn_wave_barrier();
 		if (nrows > 0) {
-			if (LEAF) gsr_sh_lin_store(reinterpret_cast<const float*>(s_sh[wave]), a.dL_dsh, a.dL_dsh_rest, wave_first, nrows, lane);
-			else gsr_sh_rows_store(s_sh[wave], a.dL_dsh, wave_first, nrows, lane);
+			if (LEAF) gsr_sh_lin_store(reinterpret_cast<const float*>(s_sh[wave]), a.dL_dsh, a.dL_dsh_rest, out_wave_first, nrows, lane);
+			else gsr_sh_rows_store(s_sh[wave], a.dL_dsh, out_wave_first, nrows, lane);
 		}
 	} else if (LEAF) {
 		if (in_range) {
@@ -416,8 +422,8 @@ __global__ void __launch_bounds__(GSR_GB_THREADS) gsr_gaussian_backward_kernel(G
 #pragma unroll
 					for (int ch = 0; ch < 3; ch++) {
 						const float v = k < used ? dsh_local[k * 3 + ch] : 0.f;
-						if (k == 0) a.dL_dsh[3 * (size_t)idx + ch] = v;
-						else a.dL_dsh_rest[((size_t)idx * (M - 1) + (k - 1)) * 3 + ch] = v;
+						if (k == 0) a.dL_dsh[3 * orow + ch] = v;
+						else a.dL_dsh_rest[(orow * (M - 1) + (k - 1)) * 3 + ch] = v;
 					}
 				}
 		}
@@ -428,21 +434,31 @@ __global__ void __launch_bounds__(GSR_GB_THREADS) gsr_gaussian_backward_kernel(G
 	if (!in_range) return;
 #pragma unroll
 	for (int k = 0; k < 3; k++) {
-		a.dL_dmean2D[3 * (size_t)idx + k] = dmean2D[k];
-		if (a.dL_dcolor) a.dL_dcolor[3 * (size_t)idx + k] = dcolor[k];
-		a.dL_dmean3D[3 * (size_t)idx + k] = dmean3D[k];
-		a.dL_dscale[3 * (size_t)idx + k] = dscale[k];
+		a.dL_dmean2D[3 * orow + k] = dmean2D[k];
+		if (a.dL_dcolor) a.dL_dcolor[3 * orow + k] = dcolor[k];
+		a.dL_dmean3D[3 * orow + k] = dmean3D[k];
+		a.dL_dscale[3 * orow + k] = dscale[k];
 	}
 #pragma unroll
 	for (int k = 0; k < 4; k++) {
-		if (a.dL_dconic) a.dL_dconic[4 * (size_t)idx + k] = dconic[k];
-		a.dL_drot[4 * (size_t)idx + k] = drot[k];
+		if (a.dL_dconic) a.dL_dconic[4 * orow + k] = dconic[k];
+		a.dL_drot[4 * orow + k] = drot[k];
 	}
 	if (a.dL_dcov3D) {
 #pragma unroll
-		for (int k = 0; k < 6; k++) a.dL_dcov3D[6 * (size_t)idx + k] = dcov[k];
+		for (int k = 0; k < 6; k++) a.dL_dcov3D[6 * orow + k] = dcov[k];
 	}
-	a.dL_dopacity[idx] = dop;
+	a.dL_dopacity[orow] = dop;
+	// ---- densification statistics of this view (train.py:157-159, scene/gaussian_model.py:599-602) ----
+	//   max_radii2D[vis] = max(max_radii2D[vis], radii[vis]);  xyz_gradient_accum[vis] += norm(viewspace.grad[vis,:2]);  denom[vis] += 1
+	if (visible) {
+		if (a.stat_xyz_gradient_accum) a.stat_xyz_gradient_accum[idx] += sqrtf(dmean2D[0] * dmean2D[0] + dmean2D[1] * dmean2D[1]);
+		if (a.stat_denom) a.stat_denom[idx] += 1.0f;
+		if (a.stat_max_radii2D) {
+			const float r = a.radii ? (float)a.radii[idx] : 0.f;
+			a.stat_max_radii2D[idx] = fmaxf(a.stat_max_radii2D[idx], r);
+		}
+	}
 }
 
 void gsr_launch_gaussian_backward(const GsrGaussianBackwardArgs& a, hipStream_t s)
@@ -452,9 +468,9 @@ void gsr_launch_gaussian_backward(const GsrGaussianBackwardArgs& a, hipStream_t 
 	int sh_via_lds = (a.shs && a.M == 16 && ((uintptr_t)a.shs & 15u) == 0 && (skip_dsh || ((uintptr_t)a.dL_dsh & 15u) == 0)) ? 1 : 0;
 	if (a.leaf) {
 		if (((uintptr_t)a.shs_rest & 15u) != 0 || (!skip_dsh && ((uintptr_t)a.dL_dsh_rest & 15u) != 0)) sh_via_lds = 0;
-		hipLaunchKernelGGL(gsr_gaussian_backward_kernel<true>, dim3((a.P + GSR_GB_THREADS - 1) / GSR_GB_THREADS), dim3(GSR_GB_THREADS), 0, s, a, sh_via_lds, skip_dsh);
+		hipLaunchKernelGGL(gsr_gaussian_backward_kernel<true>, dim3((a.count + GSR_GB_THREADS - 1) / GSR_GB_THREADS), dim3(GSR_GB_THREADS), 0, s, a, sh_via_lds, skip_dsh);
 	} else {
-		hipLaunchKernelGGL(gsr_gaussian_backward_kernel<false>, dim3((a.P + GSR_GB_THREADS - 1) / GSR_GB_THREADS), dim3(GSR_GB_THREADS), 0, s, a, sh_via_lds, skip_dsh);
+		hipLaunchKernelGGL(gsr_gaussian_backward_kernel<false>, dim3((a.count + GSR_GB_THREADS - 1) / GSR_GB_THREADS), dim3(GSR_GB_THREADS), 0, s, a, sh_via_lds, skip_dsh);
 	}
 }
 

@@ -29,7 +29,7 @@ struct __attribute__((aligned(16))) GsrSplat {
 	float cc, opacity;    // conic c, opacity (forward.cu:320)
 	float r, g;           // colour
 	float b;
-	uint32_t slot_base;   // first (Gaussian,tile) slot = point_offsets[i] - tiles_touched[i]
+	uint32_t unused;      // (the first gradient slot of the Gaussian lives in the dense GsrGeometry::slot_base array)
 	uint32_t rect_min;    // tile rect min: x | y << 16
 	uint32_t rect_wh;     // tile rect size: w | h << 16
 };

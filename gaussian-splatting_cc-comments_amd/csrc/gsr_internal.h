@@ -26,6 +26,8 @@ struct GsrGeometry {
 	uint32_t* perm;            // identity; after the depth sort: Gaussian ids in (depth, id) order
 	uint32_t* perm_alt;
 	uint32_t* tiles_touched;
+	uint2* rect;               // dense copy of the tile rectangle {x | y << 16, w | h << 16}: what the depth-ordered kernels gather
+	uint32_t* slot_base;       // first (Gaussian,tile) gradient slot = offset of the Gaussian's first instance in depth-ordered emission
 	uint8_t* clamped;
 	uint32_t* status;             // [0] prefiltered trap, [4 .. 4+GSR_COUNT_PARTS) partial instance counts
 
@@ -39,6 +41,7 @@ struct GsrImage {
 	uint32_t* n_contrib;
 	uint2* ranges;
 	uint32_t* tile_max_contrib;
+	uint32_t* tile_order;      // tiles in descending order of backward work (longest-processing-time-first dispatch)
 };
 
 struct GsrBinning {
@@ -58,7 +61,7 @@ int gsr_fail(int code, const char* fmt, ...);
 int gsr_check_hip(hipError_t e, const char* what);
 // Called after each stage: in debug mode synchronises the stream and reports kernel errors.
 int gsr_stage_done(hipStream_t s, int debug, const char* stage);
-// Per-kernel event profiling (api.hip); no-ops unless gsr_profile_begin() was called.
+// Per-kernel event profiling (api.hip); no-ops unless gsr_profile_begin() was called for this stream.
 void gsr_prof_mark_begin(hipStream_t s, const char* name);
 void gsr_prof_mark_end(hipStream_t s);
 
@@ -101,6 +104,7 @@ void gsr_launch_scan_block_sums(uint32_t* block_sums, int nb, uint32_t* total_ou
 void gsr_launch_sorted_block_sums(GsrGeometry g, int P, hipStream_t s);
 void gsr_launch_duplicate_keys(GsrGeometry g, int P, int W, uint32_t* keys, uint32_t* vals, hipStream_t s);
 void gsr_launch_tile_ranges(const uint32_t* tile_keys, int64_t R, uint2* ranges, int ntiles, uint32_t* valid, hipStream_t s);
+void gsr_launch_tile_order(GsrImage img, int ntiles, hipStream_t s);
 
 // sort.hip
 int gsr_radix_num_passes(int nbits_total);
@@ -114,12 +118,14 @@ void gsr_launch_render_forward(int W, int H, GsrImage img, const uint32_t* point
 
 // render_backward.hip
 void gsr_launch_render_backward(int W, int H, GsrImage img, const uint32_t* point_list, const GsrSplat* splat,
-                                const float* bg, const float* dL_dpix, GsrGradSlot* slots, uint8_t* slot_valid,
-                                hipStream_t s);
+                                const uint32_t* slot_base, const float* bg, const float* dL_dpix, GsrGradSlot* slots,
+                                uint8_t* slot_valid, hipStream_t s);
 
 // gaussian_backward.hip
 struct GsrGaussianBackwardArgs {
 	int P, D, M, W, H;
+	int first, count;          // the Gaussians [first, first + count) are processed (first is a multiple of 64)
+	int out_row0;              // gradient outputs are written at row (index - out_row0): 0, or `first` for per-part buffers
 	const float* means3D;
 	const float* shs;
 	const float* colors_precomp;
@@ -131,7 +137,7 @@ struct GsrGaussianBackwardArgs {
 	const float* projmatrix;
 	const float* cam_pos;
 	float tan_fovx, tan_fovy, focal_x, focal_y;
-	const int* radii;
+	const int* radii;          // may be NULL: visibility is then taken from tiles_touched (same predicate)
 	GsrGeometry g;
 	const GsrGradSlot* slots;
 	const uint8_t* slot_valid;
@@ -150,6 +156,10 @@ struct GsrGaussianBackwardArgs {
 	int leaf;
 	const float* shs_rest;
 	float* dL_dsh_rest;
+	// densification statistics (train.py:157-159, scene/gaussian_model.py:599-602), each may be NULL
+	float* stat_xyz_gradient_accum;  // [P] += ||dL_dmean2D.xy|| for visible Gaussians
+	float* stat_denom;               // [P] += 1 for visible Gaussians
+	float* stat_max_radii2D;         // [P] = max(itself, radius) for visible Gaussians
 };
 void gsr_launch_gaussian_backward(const GsrGaussianBackwardArgs& a, hipStream_t s);
 void gsr_launch_sh_grad_from_views(int P, int D, int M, int V, const float* means3D, const float* cam_pos, const float* dL_dRGB,

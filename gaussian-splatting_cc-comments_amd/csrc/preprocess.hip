@@ -52,6 +52,7 @@ __global__ void __launch_bounds__(GSR_PREPROCESS_BLOCK) gsr_preprocess_kernel(Gs
 		__builtin_amdgcn_wave_barrier();
 	}
 	uint32_t tiles = 0;
+	uint2 rect = make_uint2(0u, 0u);
 	int radius_out = 0;
 	uint32_t depth_key = 0xFFFFFFFFu;  // culled Gaussians sort behind every visible one
 	const int gx = (a.W + GSR_TILE_X - 1) / GSR_TILE_X, gy = (a.H + GSR_TILE_Y - 1) / GSR_TILE_Y;
@@ -148,12 +149,12 @@ __global__ void __launch_bounds__(GSR_PREPROCESS_BLOCK) gsr_preprocess_kernel(Gs
 			float4* rec = reinterpret_cast<float4*>(a.g.splat + idx);
 			rec[0] = make_float4(pix, piy, conic_a, conic_b);
 			rec[1] = make_float4(conic_c, LEAF ? gsr_act_sigmoid(a.opacities[idx]) : a.opacities[idx], rgb[0], rgb[1]);
-			rec[2] = make_float4(rgb[2], 0.f /* slot_base: filled after the scan */,
-			                     __uint_as_float((uint32_t)minx | ((uint32_t)miny << 16)),
-			                     __uint_as_float((uint32_t)(maxx - minx) | ((uint32_t)(maxy - miny) << 16)));
+			rect = make_uint2((uint32_t)minx | ((uint32_t)miny << 16), (uint32_t)(maxx - minx) | ((uint32_t)(maxy - miny) << 16));
+			rec[2] = make_float4(rgb[2], 0.f, __uint_as_float(rect.x), __uint_as_float(rect.y));
 		} while (0);
-		a.radii[idx] = radius_out;
+		if (a.radii) a.radii[idx] = radius_out;  // optional, cuda_rasterizer/rasterizer.h:52
 		a.g.tiles_touched[idx] = tiles;
+		a.g.rect[idx] = rect;             // dense copy: the depth-ordered kernels gather 8 bytes, not a 48-byte record
 		a.g.depth_keys[idx] = depth_key;  // inputs of the depth sort (sort.hip)
 		a.g.perm[idx] = (uint32_t)idx;
 	}

@@ -19,9 +19,10 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 
 __global__ void __launch_bounds__(64 * GSR_WAVES_PER_WG) __attribute__((amdgpu_waves_per_eu(4, 4))) gsr_render_backward_wave_kernel(
 	int W, int H, int gx, int ntiles, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
-	const GsrSplat* __restrict__ splat, const float* __restrict__ bg, const float* __restrict__ final_Ts,
-	const uint32_t* __restrict__ n_contrib, const uint32_t* __restrict__ tile_max_contrib,
-	const float* __restrict__ dL_dpixels, GsrGradSlot* __restrict__ slots, uint8_t* __restrict__ slot_valid, int cull)
+	const GsrSplat* __restrict__ splat, const uint32_t* __restrict__ slot_base, const float* __restrict__ bg,
+	const float* __restrict__ final_Ts, const uint32_t* __restrict__ n_contrib, const uint32_t* __restrict__ tile_max_contrib,
+	const uint32_t* __restrict__ tile_order, const float* __restrict__ dL_dpixels, GsrGradSlot* __restrict__ slots,
+	uint8_t* __restrict__ slot_valid, int cull)
 {
 	// per-wave staging of the surviving instances of a batch.  Every per-instance scalar that meets the
 	// float2 pixel pairs is stored TWICE, so a ds_read_b128 delivers it as an aligned register pair ready
@@ -29,8 +30,11 @@ __global__ void __launch_bounds__(64 * GSR_WAVES_PER_WG) __attribute__((amdgpu_w
 	__shared__ float4 s_rec[GSR_WAVES_PER_WG][5][64];
 	__shared__ uint32_t s_bands[GSR_WAVES_PER_WG][64];
 	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-	const int tile = blockIdx.x * GSR_WAVES_PER_WG + wave;
-	if (tile >= ntiles) return;  // wave-uniform; no barriers below
+	const int slot_id = blockIdx.x * GSR_WAVES_PER_WG + wave;
+	if (slot_id >= ntiles) return;  // wave-uniform; no barriers below
+	// workgroups are dispatched in index order: tile_order lists the tiles by descending work, so the long tiles
+	// start first and the short ones fill the end of the launch (binning.hip gsr_tile_order_kernel)
+	const int tile = (int)tile_order[slot_id];
 	float4(*rec)[64] = s_rec[wave];
 	uint32_t* recb = s_bands[wave];
 
@@ -86,9 +90,12 @@ __global__ void __launch_bounds__(64 * GSR_WAVES_PER_WG) __attribute__((amdgpu_w
 
 	// back to front: batch position q = base + lane maps to range position n - 1 - q
 	float4 ra = make_float4(0, 0, 0, 0), rb = ra, rc = ra;
+	uint32_t sbase = 0u;  // first gradient slot of the staged Gaussian (dense per-Gaussian array, cache resident)
 	if (lane < n) {
-		const float4* p = reinterpret_cast<const float4*>(splat + plist[n - 1 - lane]);
+		const uint32_t id = plist[n - 1 - lane];
+		const float4* p = reinterpret_cast<const float4*>(splat + id);
 		ra = p[0]; rb = p[1]; rc = p[2];
+		sbase = slot_base[id];
 	}
 	uint32_t id_next = (64 + lane < n) ? plist[n - 1 - (64 + lane)] : 0u;
 	const int out_index = gsr_bfly_index(lane >> 3);  // which of v[0..7] this lane's 8-lane group ends up holding
@@ -101,7 +108,7 @@ __global__ void __launch_bounds__(64 * GSR_WAVES_PER_WG) __attribute__((amdgpu_w
 		if (keep) {
 			const int pos = gsr_mbcnt(mask);
 			const uint32_t rmin = __float_as_uint(rc.z), rwh = __float_as_uint(rc.w);
-			const uint32_t slot = __float_as_uint(rc.y) + ((uint32_t)ty - (rmin >> 16)) * (rwh & 0xffffu) + ((uint32_t)tx - (rmin & 0xffffu));
+			const uint32_t slot = sbase + ((uint32_t)ty - (rmin >> 16)) * (rwh & 0xffffu) + ((uint32_t)tx - (rmin & 0xffffu));
 			rec[0][pos] = make_float4(ra.x, ra.x, ra.y, ra.y);  // mean x, y
 			rec[1][pos] = make_float4(ra.z, ra.z, ra.w, ra.w);  // conic a, b
 			rec[2][pos] = make_float4(rb.x, rb.x, rb.y, rb.y);  // conic c, opacity
@@ -112,6 +119,7 @@ __global__ void __launch_bounds__(64 * GSR_WAVES_PER_WG) __attribute__((amdgpu_w
 		if (base + 64 + lane < n) {
 			const float4* p = reinterpret_cast<const float4*>(splat + id_next);
 			ra = p[0]; rb = p[1]; rc = p[2];
+			sbase = slot_base[id_next];
 		}
 		id_next = (base + 128 + lane < n) ? plist[n - 1 - (base + 128 + lane)] : 0u;
 		__builtin_amdgcn_wave_barrier();
@@ -209,13 +217,13 @@ __global__ void __launch_bounds__(64 * GSR_WAVES_PER_WG) __attribute__((amdgpu_w
 }
 
 void gsr_launch_render_backward(int W, int H, GsrImage img, const uint32_t* point_list, const GsrSplat* splat,
-                                const float* bg, const float* dL_dpix, GsrGradSlot* slots, uint8_t* slot_valid,
-                                hipStream_t s)
+                                const uint32_t* slot_base, const float* bg, const float* dL_dpix, GsrGradSlot* slots,
+                                uint8_t* slot_valid, hipStream_t s)
 {
 	const int gx = gsr_grid_x(W), gy = gsr_grid_y(H);
 	const int ntiles = gx * gy;
 	const int nwg = (ntiles + GSR_WAVES_PER_WG - 1) / GSR_WAVES_PER_WG;
 	hipLaunchKernelGGL(gsr_render_backward_wave_kernel, dim3(nwg), dim3(64 * GSR_WAVES_PER_WG), 0, s, W, H, gx, ntiles,
-	                   img.ranges, point_list, splat, bg, img.final_T, img.n_contrib, img.tile_max_contrib, dL_dpix,
-	                   slots, slot_valid, gsr_culling_enabled());
+	                   img.ranges, point_list, splat, slot_base, bg, img.final_T, img.n_contrib, img.tile_max_contrib,
+	                   img.tile_order, dL_dpix, slots, slot_valid, gsr_culling_enabled());
 }

@@ -13,9 +13,8 @@
 // the reference's tile list is evaluated on every band), to bisect a suspected culling error.
 static inline int gsr_culling_enabled()
 {
-	static int v = -1;
-	if (v < 0) { const char* e = getenv("GSR_NO_CULL"); v = (e && e[0] == '1') ? 0 : 1; }
-	return v;
+	const char* e = getenv("GSR_NO_CULL");  // read at every launch: a test can switch it inside one process
+	return (e && e[0] == '1') ? 0 : 1;
 }
 
 #define GSR_WAVES_PER_WG 1

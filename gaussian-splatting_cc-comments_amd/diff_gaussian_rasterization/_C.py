@@ -14,21 +14,9 @@ import os
 
 import torch
 
-# tests set this to keep the internal dL_dconic tensor of the last backward call in `debug_last`
-KEEP_DEBUG = False
-debug_last = {}
-# Set by _RasterizeGaussians.backward around its call: outputs that autograd would drop anyway (dL_dcolors when the
-# colours came from SH, dL_dcov3D when the covariances came from scales/rotations, the internal dL_dconic) are not
-# computed and come back as empty tensors.  A direct caller of rasterize_gaussians_backward gets all of them, like
-# the reference's extension returns them.
-ONLY_CONSUMED_GRADS = False
-# View-parallel mode (view_parallel.skip_sh_gradient): the backward does not produce dL_dsh (returned
-# as None) and the clamp-masked dL/dRGB of the view is left in `view_parallel_last["dL_dRGB"]`
-SKIP_SH_GRAD = False
-view_parallel_last = {}
-
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(os.path.dirname(_HERE), "libgsr_hip.so")
+# GSR_HIP_LIBRARY: another build of the same C ABI (e.g. the diagnostic build of tools/tile_timing.py)
+_LIB_PATH = os.environ.get("GSR_HIP_LIBRARY") or os.path.join(os.path.dirname(_HERE), "libgsr_hip.so")
 _lib = None
 
 _vp = ctypes.c_void_p
@@ -39,12 +27,12 @@ _sz = ctypes.c_size_t
 
 
 class GeometryLayout(ctypes.Structure):
-    _fields_ = [(n, _sz) for n in ("splat", "depth_keys", "depth_keys_alt", "perm", "perm_alt", "tiles_touched",
-                                   "clamped", "status", "scan_temp", "sort_table", "total")]
+    _fields_ = [(n, _sz) for n in ("splat", "depth_keys", "depth_keys_alt", "perm", "perm_alt", "tiles_touched", "rect",
+                                   "slot_base", "clamped", "status", "scan_temp", "sort_table", "total")]
 
 
 class ImageLayout(ctypes.Structure):
-    _fields_ = [(n, _sz) for n in ("final_T", "n_contrib", "ranges", "tile_max_contrib", "total")]
+    _fields_ = [(n, _sz) for n in ("final_T", "n_contrib", "ranges", "tile_max_contrib", "tile_order", "total")]
 
 
 class BinningLayout(ctypes.Structure):
@@ -54,6 +42,19 @@ class BinningLayout(ctypes.Structure):
 
 class KernelTime(ctypes.Structure):
     _fields_ = [("name", ctypes.c_char_p), ("ms", _f)]
+
+
+class BackwardArgs(ctypes.Structure):
+    """include/gsr.h gsr_backward_args (the two-stage backward: gsr_backward_blend / gsr_backward_gaussians)"""
+    _fields_ = ([("P", _i), ("D", _i), ("M", _i), ("num_rendered", _i64), ("width", _i), ("height", _i), ("leaf", _i)] +
+                [(n, _vp) for n in ("background", "means3D", "shs", "shs_rest", "colors_precomp", "scales")] +
+                [("scale_modifier", _f)] +
+                [(n, _vp) for n in ("rotations", "cov3D_precomp", "viewmatrix", "projmatrix", "cam_pos")] +
+                [("tan_fovx", _f), ("tan_fovy", _f)] +
+                [(n, _vp) for n in ("radii", "geometry", "binning", "image", "scratch", "dL_dpix", "dL_dmean2D", "dL_dconic",
+                                    "dL_dopacity", "dL_dcolor", "dL_dmean3D", "dL_dcov3D", "dL_dsh", "dL_dsh_rest", "dL_dscale",
+                                    "dL_drot", "stat_xyz_gradient_accum", "stat_denom", "stat_max_radii2D", "stream")] +
+                [("debug", _i)])
 
 
 def library_path():
@@ -96,9 +97,16 @@ def lib():
     L.gsr_mark_visible.argtypes = [_i, _vp, _vp, _vp, _vp, _vp]
     L.gsr_sh_grad_from_views.restype = _i
     L.gsr_sh_grad_from_views.argtypes = [_i, _i, _i, _i, _vp, _vp, _vp, _i64, _vp, _vp]
+    L.gsr_backward_blend.restype = _i
+    L.gsr_backward_blend.argtypes = [ctypes.POINTER(BackwardArgs)]
+    L.gsr_backward_gaussians.restype = _i
+    L.gsr_backward_gaussians.argtypes = [ctypes.POINTER(BackwardArgs), _i, _i, _i]
     L.gsr_profile_begin.restype = _i
+    L.gsr_profile_begin.argtypes = [_vp]
+    L.gsr_profile_begin_only.restype = _i
+    L.gsr_profile_begin_only.argtypes = [_vp, ctypes.c_char_p]
     L.gsr_profile_end.restype = _i
-    L.gsr_profile_end.argtypes = [ctypes.POINTER(KernelTime), _i]
+    L.gsr_profile_end.argtypes = [_vp, ctypes.POINTER(KernelTime), _i]
     _lib = L
     return L
 
@@ -175,8 +183,19 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
 
 def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier,
                                  cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, sh, degree,
-                                 campos, geomBuffer, R, binningBuffer, imageBuffer, debug):
-    """-> (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations)"""
+                                 campos, geomBuffer, R, binningBuffer, imageBuffer, debug, *, lean=False, skip_sh=False,
+                                 debug_out=None, stats=None):
+    """-> (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations)
+
+    The 21 positional arguments and the tuple are the reference extension's.  Keyword-only extras (all per call,
+    nothing is kept between calls):
+      lean      outputs that autograd would drop anyway (dL_dcolors when the colours came from SH, dL_dcov3D when the
+                covariances came from scales/rotations, the internal dL_dconic) are not computed: empty tensors
+      skip_sh   view-parallel mode: dL_dsh is not produced (None) and dL_dcolors carries the clamp-masked dL/dRGB
+                of the view, the input of sh_grad_from_views()
+      debug_out dict that receives the internal "dL_dconic" tensor (tests)
+      stats     (xyz_gradient_accum, denom, max_radii2D) float32 [P] tensors updated in place for the Gaussians
+                visible in this view (train.py:157-159, gaussian_model.py:599-602); any of them may be None"""
     L = lib()
     dev = means3D.device
     P = int(means3D.size(0))
@@ -188,8 +207,8 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
         alloc = torch.zeros if P == 0 else torch.empty
         dL_dmeans3D = alloc((P, 3), **f32)
         dL_dmeans2D = alloc((P, 3), **f32)
-        skip_sh = bool(SKIP_SH_GRAD) and M > 0
-        lean = bool(ONLY_CONSUMED_GRADS) and not KEEP_DEBUG
+        skip_sh = bool(skip_sh) and M > 0
+        lean = bool(lean) and debug_out is None
         none = torch.empty((0,), **f32)
         dL_dcolors = alloc((P, 3), **f32) if (not lean or colors.numel() != 0 or skip_sh) else none
         dL_dconic = alloc((P, 2, 2), **f32) if not lean else none
@@ -205,24 +224,83 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
                 _dev_f32(t, dev, "input") for t in (background, colors, scales, rotations, cov3D_precomp, sh, viewmatrix,
                                                     projmatrix, campos))
             scratch = torch.empty((L.gsr_backward_scratch_bytes(P, int(R)),), dtype=torch.uint8, device=dev)
-            _check(L.gsr_backward(P, int(degree), M, int(R), W, H, _ptr(background), _ptr(means3D), _ptr(sh), _ptr(colors),
-                                  _ptr(scales), float(scale_modifier), _ptr(rotations), _ptr(cov3D_precomp),
-                                  _ptr(viewmatrix), _ptr(projmatrix), _ptr(campos), float(tan_fovx), float(tan_fovy),
-                                  _ptr(radii), _ptr(geomBuffer), _ptr(binningBuffer), _ptr(imageBuffer), _ptr(scratch),
-                                  _ptr(dL_dout_color), _ptr(dL_dmeans2D), _ptr(dL_dconic), _ptr(dL_dopacity),
-                                  _ptr(dL_dcolors), _ptr(dL_dmeans3D), _ptr(dL_dcov3D), _ptr(dL_dsh), _ptr(dL_dscales),
-                                  _ptr(dL_drotations), _stream(dev), int(bool(debug))))
+            if stats is None:
+                _check(L.gsr_backward(P, int(degree), M, int(R), W, H, _ptr(background), _ptr(means3D), _ptr(sh), _ptr(colors),
+                                      _ptr(scales), float(scale_modifier), _ptr(rotations), _ptr(cov3D_precomp),
+                                      _ptr(viewmatrix), _ptr(projmatrix), _ptr(campos), float(tan_fovx), float(tan_fovy),
+                                      _ptr(radii), _ptr(geomBuffer), _ptr(binningBuffer), _ptr(imageBuffer), _ptr(scratch),
+                                      _ptr(dL_dout_color), _ptr(dL_dmeans2D), _ptr(dL_dconic), _ptr(dL_dopacity),
+                                      _ptr(dL_dcolors), _ptr(dL_dmeans3D), _ptr(dL_dcov3D), _ptr(dL_dsh), _ptr(dL_dscales),
+                                      _ptr(dL_drotations), _stream(dev), int(bool(debug))))
+            else:
+                a = backward_args(P=P, D=int(degree), M=M, R=int(R), W=W, H=H, leaf=0, background=background, means3D=means3D,
+                                  shs=sh, colors_precomp=colors, scales=scales, scale_modifier=scale_modifier,
+                                  rotations=rotations, cov3D_precomp=cov3D_precomp, viewmatrix=viewmatrix,
+                                  projmatrix=projmatrix, cam_pos=campos, tan_fovx=tan_fovx, tan_fovy=tan_fovy, radii=radii,
+                                  geometry=geomBuffer, binning=binningBuffer, image=imageBuffer, scratch=scratch,
+                                  dL_dpix=dL_dout_color, debug=debug, device=dev)
+                set_backward_outputs(a, dL_dmean2D=dL_dmeans2D, dL_dconic=dL_dconic, dL_dopacity=dL_dopacity,
+                                     dL_dcolor=dL_dcolors, dL_dmean3D=dL_dmeans3D, dL_dcov3D=dL_dcov3D, dL_dsh=dL_dsh,
+                                     dL_dscale=dL_dscales, dL_drot=dL_drotations)
+                set_backward_stats(a, stats, P, dev)
+                backward_blend(a)
+                backward_gaussians(a, 0, P, 0)
             scratch.record_stream(torch.cuda.current_stream(dev))
-    if KEEP_DEBUG:
-        debug_last["dL_dconic"] = dL_dconic
-    if skip_sh:
-        view_parallel_last["dL_dRGB"] = dL_dcolors
+    if debug_out is not None:
+        debug_out["dL_dconic"] = dL_dconic
     return dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations
 
 
-def sh_grad_from_views(means3D, cam_pos, dL_dRGB, degree, M):
+# ---- the backward in two stages (include/gsr.h gsr_backward_blend / gsr_backward_gaussians) ------------------
+def backward_args(*, P, D, M, R, W, H, leaf, background, means3D, shs, scales, scale_modifier, rotations, viewmatrix,
+                  projmatrix, cam_pos, tan_fovx, tan_fovy, radii, geometry, binning, image, scratch, dL_dpix, debug, device,
+                  shs_rest=None, colors_precomp=None, cov3D_precomp=None):
+    """Input side of a gsr_backward_args; the gradient pointers are set with set_backward_outputs().  The tensors must
+    stay alive (and contiguous float32 on `device`) until the calls that use the struct have been enqueued."""
+    a = BackwardArgs()
+    a.P, a.D, a.M, a.num_rendered, a.width, a.height, a.leaf = int(P), int(D), int(M), int(R), int(W), int(H), int(leaf)
+    for name, t in (("background", background), ("means3D", means3D), ("shs", shs), ("shs_rest", shs_rest),
+                    ("colors_precomp", colors_precomp), ("scales", scales), ("rotations", rotations),
+                    ("cov3D_precomp", cov3D_precomp), ("viewmatrix", viewmatrix), ("projmatrix", projmatrix),
+                    ("cam_pos", cam_pos), ("radii", radii), ("geometry", geometry), ("binning", binning), ("image", image),
+                    ("scratch", scratch), ("dL_dpix", dL_dpix)):
+        setattr(a, name, _ptr(t))
+    a.scale_modifier, a.tan_fovx, a.tan_fovy = float(scale_modifier), float(tan_fovx), float(tan_fovy)
+    a.stream = _stream(device)
+    a.debug = int(bool(debug))
+    return a
+
+
+def set_backward_outputs(a, **ptrs):
+    """ptrs: field name -> tensor (its data_ptr), int address, or None.  With out_row0 = first, an address is where
+    the row of Gaussian `first` goes."""
+    for name, t in ptrs.items():
+        setattr(a, name, t if (t is None or isinstance(t, int)) else _ptr(t))
+
+
+def set_backward_stats(a, stats, P, device):
+    if stats is None:
+        return
+    for name, t in zip(("stat_xyz_gradient_accum", "stat_denom", "stat_max_radii2D"), stats):
+        if t is None:
+            continue
+        if t.device != device or t.dtype != torch.float32 or t.numel() != P or not t.is_contiguous():
+            raise RuntimeError(f"{name} must be a contiguous float32 tensor with P = {P} elements on {device}")
+        setattr(a, name, t.data_ptr())
+
+
+def backward_blend(a):
+    _check(lib().gsr_backward_blend(ctypes.byref(a)))
+
+
+def backward_gaussians(a, first, count, out_row0=0):
+    _check(lib().gsr_backward_gaussians(ctypes.byref(a), int(first), int(count), int(out_row0)))
+
+
+def sh_grad_from_views(means3D, cam_pos, dL_dRGB, degree, M, out=None):
     """dL_dsh (P,M,3) summed over V views from their clamp-masked dL/dRGB (V,P,3) and camera
-    positions (V,3): include/gsr.h gsr_sh_grad_from_views."""
+    positions (V,3): include/gsr.h gsr_sh_grad_from_views.  out: optional contiguous (P,M,3) destination (a row
+    range of a larger tensor when the caller works part by part)."""
     if not means3D.is_cuda:
         raise RuntimeError("means3D must be a HIP (cuda) tensor; the HIP rasterizer has no CPU path")
     L = lib()
@@ -237,7 +315,10 @@ def sh_grad_from_views(means3D, cam_pos, dL_dRGB, degree, M):
         raise RuntimeError("dL_dRGB must be a float32 tensor on the device of means3D")
     means3D, cam_pos = (_dev_f32(t, dev, n) for t, n in ((means3D, "means3D"), (cam_pos, "cam_pos")))
     with torch.cuda.device(dev):
-        out = torch.empty((P, M, 3), dtype=torch.float32, device=dev)
+        if out is None:
+            out = torch.empty((P, M, 3), dtype=torch.float32, device=dev)
+        elif out.shape != (P, M, 3) or out.dtype != torch.float32 or out.device != dev or not out.is_contiguous():
+            raise RuntimeError("sh_grad_from_views: out must be a contiguous float32 (P,M,3) tensor on the device of means3D")
         _check(L.gsr_sh_grad_from_views(P, int(degree), int(M), V, _ptr(means3D), _ptr(cam_pos), _ptr(dL_dRGB), view_stride,
                                         _ptr(out), _stream(dev)))
     return out
@@ -279,15 +360,15 @@ def binning_layout(P, R, W, H):
     return o
 
 
-def profile_begin(only=None):
-    """Start recording per-stage HIP events; `only` = name of the single stage to record."""
-    if only is None:
-        lib().gsr_profile_begin()
-    else:
-        lib().gsr_profile_begin_only(ctypes.c_char_p(only.encode()))
+def profile_begin(only=None, device=None):
+    """Start recording per-stage HIP events for calls made on `device`'s current stream; `only` = name of the
+    single stage to record."""
+    stream = _stream(torch.device("cuda", torch.cuda.current_device()) if device is None else device)
+    _check(lib().gsr_profile_begin_only(stream, None if only is None else only.encode()))
 
 
-def profile_end(capacity=256):
+def profile_end(capacity=256, device=None):
+    stream = _stream(torch.device("cuda", torch.cuda.current_device()) if device is None else device)
     arr = (KernelTime * capacity)()
-    n = lib().gsr_profile_end(arr, capacity)
+    n = lib().gsr_profile_end(stream, arr, capacity)
     return [(arr[k].name.decode(), float(arr[k].ms)) for k in range(n)]

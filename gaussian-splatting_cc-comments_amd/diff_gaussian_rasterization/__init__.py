@@ -21,16 +21,16 @@ def cpu_deep_copy_tuple(input_tuple):
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                        raster_settings):
-    """reference __init__.py:22-45"""
+                        raster_settings, densify_stats=None):
+    """reference __init__.py:22-45 (+ the optional densification-statistics tensors, see GaussianRasterizer)"""
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
-                                     cov3Ds_precomp, raster_settings)
+                                     cov3Ds_precomp, raster_settings, densify_stats)
 
 
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                raster_settings):
+                raster_settings, densify_stats=None):
         # argument order of _C.rasterize_gaussians: reference __init__.py:64-84
         args = (
             raster_settings.bg,
@@ -65,6 +65,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer = _C.rasterize_gaussians(*args)
 
         ctx.raster_settings = raster_settings
+        ctx.densify_stats = densify_stats
         ctx.num_rendered = num_rendered
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer,
                               binningBuffer, imgBuffer)
@@ -106,19 +107,15 @@ class _RasterizeGaussians(torch.autograd.Function):
             cpu_args = cpu_deep_copy_tuple(args)
             try:
                 (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh,
-                 grad_scales, grad_rotations) = _C.rasterize_gaussians_backward(*args)
+                 grad_scales, grad_rotations) = _C.rasterize_gaussians_backward(*args, stats=ctx.densify_stats)
             except Exception as ex:
                 torch.save(cpu_args, "snapshot_bw.dump")
                 print("\nAn error occured in backward. Writing snapshot_bw.dump for debugging.\n")
                 raise ex
         else:
-            # gradients of inputs that were not provided have no consumer below: the binding may skip them
-            prev, _C.ONLY_CONSUMED_GRADS = _C.ONLY_CONSUMED_GRADS, True
-            try:
-                (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh,
-                 grad_scales, grad_rotations) = _C.rasterize_gaussians_backward(*args)
-            finally:
-                _C.ONLY_CONSUMED_GRADS = prev
+            # gradients of inputs that were not provided have no consumer below: the binding skips them
+            (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh,
+             grad_scales, grad_rotations) = _C.rasterize_gaussians_backward(*args, lean=True, stats=ctx.densify_stats)
 
         # gradient order: reference __init__.py:154-164
         grads = (
@@ -130,6 +127,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             grad_scales if scales.numel() != 0 else None,
             grad_rotations if rotations.numel() != 0 else None,
             grad_cov3Ds_precomp if cov3Ds_precomp.numel() != 0 else None,
+            None,
             None,
         )
         return grads
@@ -152,11 +150,16 @@ class GaussianRasterizationSettings(NamedTuple):
 
 
 class GaussianRasterizer(nn.Module):
-    """reference __init__.py:182-258"""
+    """reference __init__.py:182-258.
 
-    def __init__(self, raster_settings):
+    densify_stats (extension, optional): (xyz_gradient_accum, denom, max_radii2D) float32 [P] tensors that the
+    backward's per-Gaussian kernel updates in place for the Gaussians visible in this view -- the bookkeeping of
+    train.py:157-159 / scene/gaussian_model.py:599-602 without separate passes (view_parallel.DensificationStats)."""
+
+    def __init__(self, raster_settings, densify_stats=None):
         super().__init__()
         self.raster_settings = raster_settings
+        self.densify_stats = densify_stats
 
     def markVisible(self, positions):
         # Mark visible points (based on frustum culling for camera) with a boolean
@@ -188,4 +191,4 @@ class GaussianRasterizer(nn.Module):
             cov3D_precomp = torch.Tensor([])
 
         return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
-                                   cov3D_precomp, raster_settings)
+                                   cov3D_precomp, raster_settings, self.densify_stats)

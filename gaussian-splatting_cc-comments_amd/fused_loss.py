@@ -55,8 +55,9 @@ class _L1SSIMLoss(torch.autograd.Function):
     def forward(ctx, image, gt, lambda_dssim):
         vals, grad = l1_ssim_loss_and_grad(image, gt, lambda_dssim, want_grad=image.requires_grad)
         ctx.save_for_backward(grad if grad is not None else torch.empty(0, device=image.device))
-        ctx.mark_non_differentiable(vals[1:])
-        return vals[0], vals[1], vals[2]
+        loss, l1, s = vals[0], vals[1], vals[2]
+        ctx.mark_non_differentiable(l1, s)   # the very objects that are returned: Ll1 and ssim are for logging only
+        return loss, l1, s
 
     @staticmethod
     def backward(ctx, g_loss, g_l1, g_ssim):

@@ -52,48 +52,70 @@ def _f32(t, dev, what):
     return t.contiguous()
 
 
+def leaf_forward(xyz, features_dc, features_rest, opacity, scaling, rotation, raster_settings):
+    """Forward from the raw leaves -> (num_rendered, color, radii, geom, binning, img, M, contiguous inputs)."""
+    if xyz.ndimension() != 2 or xyz.size(1) != 3:
+        raise RuntimeError("means3D must have dimensions (num_points, 3)")
+    L = _lib()
+    dev = xyz.device
+    st = raster_settings
+    P, H, W = int(xyz.size(0)), int(st.image_height), int(st.image_width)
+    xyz, features_dc, opacity, scaling, rotation = (_f32(t, dev, n) for t, n in (
+        (xyz, "xyz"), (features_dc, "features_dc"), (opacity, "opacity"), (scaling, "scaling"), (rotation, "rotation")))
+    M = 1 + (int(features_rest.size(1)) if features_rest.numel() else 0)
+    if features_dc.shape != (P, 1, 3) or (M > 1 and features_rest.shape != (P, M - 1, 3)):
+        raise RuntimeError(f"features_dc must be (P,1,3) and features_rest (P,M-1,3); got {tuple(features_dc.shape)}, "
+                           f"{tuple(features_rest.shape)}")
+    features_rest = _f32(features_rest, dev, "features_rest") if M > 1 else features_rest
+    bg, view, proj, campos = (_f32(t, dev, n) for t, n in ((st.bg, "bg"), (st.viewmatrix, "viewmatrix"),
+                                                           (st.projmatrix, "projmatrix"), (st.campos, "campos")))
+    byte = dict(dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        color = (torch.zeros if P == 0 else torch.empty)((3, H, W), dtype=torch.float32, device=dev)
+        radii = torch.empty((P,), dtype=torch.int32, device=dev)
+        geom = torch.empty((L.gsr_geometry_bytes(P) if P else 0,), **byte)
+        img = torch.empty((L.gsr_image_bytes(W, H) if P else 0,), **byte)
+        binning = torch.empty((0,), **byte)
+        R = 0
+        if P:
+            Rv = _i64(0)
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            _C._check(L.gsr_forward_preprocess_leaf(
+                P, int(st.sh_degree), M, W, H, xyz.data_ptr(), features_dc.data_ptr(), _C._ptr(features_rest),
+                opacity.data_ptr(), scaling.data_ptr(), float(st.scale_modifier), rotation.data_ptr(), view.data_ptr(),
+                proj.data_ptr(), campos.data_ptr(), float(st.tanfovx), float(st.tanfovy), int(bool(st.prefiltered)),
+                radii.data_ptr(), geom.data_ptr(), ctypes.byref(Rv), stream, int(bool(st.debug))))
+            R = int(Rv.value)
+            binning = torch.empty((L.gsr_binning_bytes(P, R, W, H),), **byte)
+            _C._check(L.gsr_forward_render(P, R, W, H, bg.data_ptr(), radii.data_ptr(), geom.data_ptr(), _C._ptr(binning),
+                                           img.data_ptr(), color.data_ptr(), stream, int(bool(st.debug))))
+    return R, color, radii, geom, binning, img, M, (xyz, features_dc, features_rest, scaling, rotation)
+
+
+def leaf_backward_args(st, R, M, xyz, features_dc, features_rest, scaling, rotation, radii, geom, binning, img, scratch, grad_color):
+    """gsr_backward_args (leaf = 1) for a state produced by leaf_forward(); gradient pointers still unset."""
+    dev = xyz.device
+    bg, view, proj, campos = (_f32(t, dev, "settings") for t in (st.bg, st.viewmatrix, st.projmatrix, st.campos))
+    a = _C.backward_args(P=int(xyz.size(0)), D=int(st.sh_degree), M=M, R=R, W=int(st.image_width), H=int(st.image_height), leaf=1,
+                         background=bg, means3D=xyz, shs=features_dc, shs_rest=features_rest, scales=scaling,
+                         scale_modifier=st.scale_modifier, rotations=rotation, viewmatrix=view, projmatrix=proj, cam_pos=campos,
+                         tan_fovx=st.tanfovx, tan_fovy=st.tanfovy, radii=radii, geometry=geom, binning=binning, image=img,
+                         scratch=scratch, dL_dpix=grad_color, debug=st.debug, device=dev)
+    a._keep = (bg, view, proj, campos)  # alive as long as the struct
+    return a
+
+
 class _RasterizeLeafGaussians(torch.autograd.Function):
     """(xyz, means2D, _features_dc, _features_rest, _opacity, _scaling, _rotation) -> (color, radii); the same
-    contract as diff_gaussian_rasterization._RasterizeGaussians with the activations folded in."""
+    contract as diff_gaussian_rasterization._RasterizeGaussians with the activations folded in.
+    `stats` (optional): (xyz_gradient_accum, denom, max_radii2D) float32 [P] tensors updated in place by the
+    backward for the Gaussians visible in this view (train.py:157-159, gaussian_model.py:599-602)."""
 
     @staticmethod
-    def forward(ctx, xyz, means2D, features_dc, features_rest, opacity, scaling, rotation, raster_settings):
-        if xyz.ndimension() != 2 or xyz.size(1) != 3:
-            raise RuntimeError("means3D must have dimensions (num_points, 3)")
-        L = _lib()
-        dev = xyz.device
-        st = raster_settings
-        P, H, W = int(xyz.size(0)), int(st.image_height), int(st.image_width)
-        xyz, features_dc, opacity, scaling, rotation = (_f32(t, dev, n) for t, n in (
-            (xyz, "xyz"), (features_dc, "features_dc"), (opacity, "opacity"), (scaling, "scaling"), (rotation, "rotation")))
-        M = 1 + (int(features_rest.size(1)) if features_rest.numel() else 0)
-        if features_dc.shape != (P, 1, 3) or (M > 1 and features_rest.shape != (P, M - 1, 3)):
-            raise RuntimeError(f"features_dc must be (P,1,3) and features_rest (P,M-1,3); got {tuple(features_dc.shape)}, "
-                               f"{tuple(features_rest.shape)}")
-        features_rest = _f32(features_rest, dev, "features_rest") if M > 1 else features_rest
-        bg, view, proj, campos = (_f32(t, dev, n) for t, n in ((st.bg, "bg"), (st.viewmatrix, "viewmatrix"),
-                                                               (st.projmatrix, "projmatrix"), (st.campos, "campos")))
-        byte = dict(dtype=torch.uint8, device=dev)
-        with torch.cuda.device(dev):
-            color = (torch.zeros if P == 0 else torch.empty)((3, H, W), dtype=torch.float32, device=dev)
-            radii = torch.empty((P,), dtype=torch.int32, device=dev)
-            geom = torch.empty((L.gsr_geometry_bytes(P) if P else 0,), **byte)
-            img = torch.empty((L.gsr_image_bytes(W, H) if P else 0,), **byte)
-            binning = torch.empty((0,), **byte)
-            R = 0
-            if P:
-                Rv = _i64(0)
-                stream = torch.cuda.current_stream(dev).cuda_stream
-                _C._check(L.gsr_forward_preprocess_leaf(
-                    P, int(st.sh_degree), M, W, H, xyz.data_ptr(), features_dc.data_ptr(), _C._ptr(features_rest),
-                    opacity.data_ptr(), scaling.data_ptr(), float(st.scale_modifier), rotation.data_ptr(), view.data_ptr(),
-                    proj.data_ptr(), campos.data_ptr(), float(st.tanfovx), float(st.tanfovy), int(bool(st.prefiltered)),
-                    radii.data_ptr(), geom.data_ptr(), ctypes.byref(Rv), stream, int(bool(st.debug))))
-                R = int(Rv.value)
-                binning = torch.empty((L.gsr_binning_bytes(P, R, W, H),), **byte)
-                _C._check(L.gsr_forward_render(P, R, W, H, bg.data_ptr(), radii.data_ptr(), geom.data_ptr(), _C._ptr(binning),
-                                               img.data_ptr(), color.data_ptr(), stream, int(bool(st.debug))))
-        ctx.raster_settings, ctx.num_rendered, ctx.M = st, R, M
+    def forward(ctx, xyz, means2D, features_dc, features_rest, opacity, scaling, rotation, raster_settings, stats=None):
+        R, color, radii, geom, binning, img, M, (xyz, features_dc, features_rest, scaling, rotation) = leaf_forward(
+            xyz, features_dc, features_rest, opacity, scaling, rotation, raster_settings)
+        ctx.raster_settings, ctx.num_rendered, ctx.M, ctx.stats = raster_settings, R, M, stats
         ctx.save_for_backward(xyz, features_dc, features_rest, scaling, rotation, radii, geom, binning, img)
         ctx.mark_non_differentiable(radii)
         return color, radii
@@ -104,39 +126,33 @@ class _RasterizeLeafGaussians(torch.autograd.Function):
         st, R, M = ctx.raster_settings, ctx.num_rendered, ctx.M
         xyz, features_dc, features_rest, scaling, rotation, radii, geom, binning, img = ctx.saved_tensors
         dev = xyz.device
-        P, H, W = int(xyz.size(0)), int(st.image_height), int(st.image_width)
+        P = int(xyz.size(0))
         f32 = dict(dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             alloc = torch.zeros if P == 0 else torch.empty
             d_means2D, d_xyz = alloc((P, 3), **f32), alloc((P, 3), **f32)
-            skip_sh = bool(_C.SKIP_SH_GRAD)
-            d_dc = None if skip_sh else alloc((P, 1, 3), **f32)
-            d_rest = None if skip_sh else alloc((P, M - 1, 3), **f32)
-            d_rgb = alloc((P, 3), **f32) if skip_sh else None
+            d_dc, d_rest = alloc((P, 1, 3), **f32), alloc((P, M - 1, 3), **f32)
             d_opacity, d_scaling, d_rotation = alloc((P, 1), **f32), alloc((P, 3), **f32), alloc((P, 4), **f32)
             if P:
                 grad_color = _f32(grad_color, dev, "dL_dout_color")
-                bg, view, proj, campos = (_f32(t, dev, "settings") for t in (st.bg, st.viewmatrix, st.projmatrix, st.campos))
                 scratch = torch.empty((L.gsr_backward_scratch_bytes(P, R),), dtype=torch.uint8, device=dev)
-                _C._check(L.gsr_backward_leaf(
-                    P, int(st.sh_degree), M, R, W, H, bg.data_ptr(), xyz.data_ptr(), features_dc.data_ptr(),
-                    _C._ptr(features_rest), scaling.data_ptr(), float(st.scale_modifier), rotation.data_ptr(), view.data_ptr(),
-                    proj.data_ptr(), campos.data_ptr(), float(st.tanfovx), float(st.tanfovy), radii.data_ptr(), geom.data_ptr(),
-                    _C._ptr(binning), img.data_ptr(), _C._ptr(scratch), grad_color.data_ptr(), d_means2D.data_ptr(),
-                    d_xyz.data_ptr(), _C._ptr(d_dc), _C._ptr(d_rest), d_opacity.data_ptr(), d_scaling.data_ptr(),
-                    d_rotation.data_ptr(), _C._ptr(d_rgb), torch.cuda.current_stream(dev).cuda_stream, int(bool(st.debug))))
+                a = leaf_backward_args(st, R, M, xyz, features_dc, features_rest, scaling, rotation, radii, geom, binning, img,
+                                       scratch, grad_color)
+                _C.set_backward_outputs(a, dL_dmean2D=d_means2D, dL_dmean3D=d_xyz, dL_dsh=d_dc, dL_dsh_rest=d_rest,
+                                        dL_dopacity=d_opacity, dL_dscale=d_scaling, dL_drot=d_rotation)
+                _C.set_backward_stats(a, ctx.stats, P, dev)
+                _C.backward_blend(a)
+                _C.backward_gaussians(a, 0, P, 0)
                 scratch.record_stream(torch.cuda.current_stream(dev))
-        if skip_sh:
-            _C.view_parallel_last["dL_dRGB"] = d_rgb
-        return d_xyz, d_means2D, d_dc, d_rest, d_opacity, d_scaling, d_rotation, None
+        return d_xyz, d_means2D, d_dc, d_rest, d_opacity, d_scaling, d_rotation, None, None
 
 
-def rasterize_leaf_gaussians(xyz, means2D, features_dc, features_rest, opacity, scaling, rotation, raster_settings):
+def rasterize_leaf_gaussians(xyz, means2D, features_dc, features_rest, opacity, scaling, rotation, raster_settings, stats=None):
     """Equivalent to
         GaussianRasterizer(raster_settings)(means3D=xyz, means2D=means2D, shs=cat(features_dc, features_rest, 1),
             opacities=sigmoid(opacity), scales=exp(scaling), rotations=normalize(rotation))
     -> (color (3,H,W), radii (P,) int32)."""
-    return _RasterizeLeafGaussians.apply(xyz, means2D, features_dc, features_rest, opacity, scaling, rotation, raster_settings)
+    return _RasterizeLeafGaussians.apply(xyz, means2D, features_dc, features_rest, opacity, scaling, rotation, raster_settings, stats)
 
 
 class FusedAdam(torch.optim.Optimizer):

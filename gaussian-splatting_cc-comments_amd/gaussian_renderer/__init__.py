@@ -49,8 +49,9 @@ def _result(image, screenspace_points, radii):
     return {"render": image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0, "radii": radii}
 
 
-def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, override_color=None):
-    """Render the scene seen from `viewpoint_camera`.  `bg_color` must live on the GPU."""
+def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, override_color=None, densify_stats=None):
+    """Render the scene seen from `viewpoint_camera`.  `bg_color` must live on the GPU.
+    densify_stats (extension): see GaussianRasterizer -- the statistics of train.py:157-159 updated by the backward."""
     xyz = pc.get_xyz
     # carrier of the screen-space gradient: zeros, a non-leaf that keeps its grad
     screenspace_points = torch.zeros_like(xyz, dtype=xyz.dtype, requires_grad=True, device=xyz.device) + 0
@@ -65,7 +66,7 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
     if getattr(pipe, "fused_activations", False) and override_color is None and not python_cov and not python_sh:
         from fused_params import rasterize_leaf_gaussians
         image, radii = rasterize_leaf_gaussians(pc._xyz, screenspace_points, pc._features_dc, pc._features_rest, pc._opacity,
-                                                pc._scaling, pc._rotation, settings)
+                                                pc._scaling, pc._rotation, settings, densify_stats)
         return _result(image, screenspace_points, radii)
 
     inputs = dict(means3D=xyz, means2D=screenspace_points, opacities=pc.get_opacity,
@@ -81,5 +82,5 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
     else:
         inputs["shs"] = pc.get_features
 
-    image, radii = GaussianRasterizer(raster_settings=settings)(**inputs)
+    image, radii = GaussianRasterizer(raster_settings=settings, densify_stats=densify_stats)(**inputs)
     return _result(image, screenspace_points, radii)

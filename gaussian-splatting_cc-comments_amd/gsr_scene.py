@@ -75,11 +75,14 @@ def make_camera(W, H, fovx=1.0, R: Optional[np.ndarray] = None, T: Optional[np.n
     tanfovx = math.tan(fovx * 0.5)
     tanfovy = tanfovx * H / W
     fovy = 2.0 * math.atan(tanfovy)
-    wvt = torch.tensor(world_to_view(R, T)).transpose(0, 1).contiguous()
+    # exactly the reference's sequence of operations on exactly its tensor layouts: the inverse of the TRANSPOSED VIEW
+    # (not of a contiguous copy: LAPACK then sees the other storage order and the centre differs in the last bit --
+    # tests/golden/camera_class_golden.npz)
+    wvt = torch.tensor(world_to_view(R, T)).transpose(0, 1)
     proj = projection_matrix(znear, zfar, fovx, fovy).transpose(0, 1)
     full = (wvt.unsqueeze(0).bmm(proj.unsqueeze(0))).squeeze(0).contiguous()
     center = wvt.inverse()[3, :3].contiguous()
-    return Camera(W, H, fovx, fovy, wvt, full, center)
+    return Camera(W, H, fovx, fovy, wvt.contiguous(), full, center)
 
 
 def ring_camera(W, H, k, n=8, radius=4.0, fovx=1.0) -> Camera:

@@ -61,6 +61,8 @@ typedef struct {
 	size_t perm;           /* [P] u32 Gaussian ids in (depth, id) order */
 	size_t perm_alt;       /* [P] u32 sort ping-pong */
 	size_t tiles_touched;  /* [P] u32 */
+	size_t rect;           /* [P] uint2: tile rectangle {min x | min y << 16, width | height << 16} (dense copy of the record's) */
+	size_t slot_base;      /* [P] u32: first gradient slot of the Gaussian = offset of its first instance in depth-ordered emission */
 	size_t clamped;        /* [P] u8 bit c set = colour channel c was clamped at 0 */
 	size_t status;         /* u32 device status words (0: prefiltered trap; 4..67: partial instance counts) */
 	size_t scan_temp;      /* per-workgroup tile counts: original order, then depth order */
@@ -73,6 +75,7 @@ typedef struct {
 	size_t n_contrib;      /* [W*H] u32 */
 	size_t ranges;         /* [tiles] uint2 */
 	size_t tile_max_contrib; /* [tiles] u32 = max n_contrib over the tile's pixels */
+	size_t tile_order;     /* [tiles] u32: tile ids in descending order of backward work (written by the backward) */
 	size_t total;
 } gsr_image_layout;
 
@@ -96,7 +99,8 @@ int gsr_binning_layout_of(int P, int64_t num_rendered, int width, int height, gs
  * CudaRasterizer::Rasterizer::forward (cuda_rasterizer/rasterizer_impl.cu:227-331:
  * FORWARD::preprocess, cub InclusiveSum, the blocking cudaMemcpy of num_rendered).  Blocks only
  * until `*num_rendered_host` is valid.
- *   radii [P] int32 out (0 for culled Gaussians); geometry: gsr_geometry_bytes(P) bytes.
+ *   radii [P] int32 out (0 for culled Gaussians), or NULL when the caller does not want them
+ *   (`int* radii = nullptr`, cuda_rasterizer/rasterizer.h:52); geometry: gsr_geometry_bytes(P) bytes.
  */
 int gsr_forward_preprocess(
 	int P, int D, int M,
@@ -130,7 +134,7 @@ int gsr_forward_render(
 	int P, int64_t num_rendered,
 	int width, int height,
 	const float* background,     /* [3] */
-	const int* radii,
+	const int* radii,            /* unused (kept for symmetry with Rasterizer::forward); may be NULL */
 	void* geometry, void* binning, void* image,
 	float* out_color,
 	void* stream, int debug);
@@ -148,6 +152,8 @@ int gsr_forward_render(
  * View-parallel mode: with shs given and dL_dsh == NULL the SH gradient is not produced and
  * dL_dcolor receives dL/dRGB with the channels the forward clamped at 0 zeroed -- the 3 floats per
  * Gaussian that gsr_sh_grad_from_views() needs; every other output is unchanged.
+ * radii may be NULL (`const int* radii = nullptr`, cuda_rasterizer/rasterizer.h:69): visibility is then
+ * taken from the geometry state (radii > 0 <=> tiles_touched > 0, forward.cu:300-301).
  */
 int gsr_backward(
 	int P, int D, int M, int64_t num_rendered,
@@ -178,6 +184,55 @@ int gsr_backward(
 	float* dL_dscale,
 	float* dL_drot,
 	void* stream, int debug);
+
+/*
+ * The backward in two stages, for callers that pipeline it.  gsr_backward() / gsr_backward_leaf() are
+ * gsr_backward_blend() followed by gsr_backward_gaussians() over all P Gaussians.
+ *   gsr_backward_blend      BACKWARD::render (rasterizer_impl.cu:470-495): per-tile blend gradients into `scratch`.
+ *   gsr_backward_gaussians  the per-Gaussian rest (computeCov2DCUDA + BACKWARD::preprocess, :500-517) for the
+ *                           Gaussians [first, first + count), first a multiple of 64 (count may end anywhere).
+ *                           A view-parallel caller runs it part by part and starts the gradient exchange of a
+ *                           finished part while the next one computes.  Gradient outputs are written at row
+ *                           (index - out_row0): out_row0 = 0 for whole-scene tensors, = first when each part
+ *                           has a buffer of its own; inputs and statistics are always indexed by Gaussian.
+ * leaf = 0: the fields mean what gsr_backward()'s arguments of the same name mean (shs_rest, dL_dsh_rest unused);
+ * leaf = 1: gsr_backward_leaf() semantics: means3D = xyz, shs = features_dc, shs_rest = features_rest,
+ *           scales = log_scales, rotations = raw_rotations, dL_dsh / dL_dsh_rest = the two feature gradients,
+ *           dL_dopacity / dL_dscale / dL_drot = gradients w.r.t. the raw leaves, dL_dcolor = optional dL_dRGB.
+ * Densification statistics (train.py:157-159, scene/gaussian_model.py:599-602), each [P] or NULL,
+ * updated in place for the Gaussians visible in this view (radii > 0):
+ *   stat_max_radii2D = max(stat_max_radii2D, radii);  stat_xyz_gradient_accum += ||dL_dmean2D.xy||;  stat_denom += 1
+ * (stat_max_radii2D needs radii != NULL).
+ */
+typedef struct {
+	int P, D, M;
+	int64_t num_rendered;
+	int width, height;
+	int leaf;
+	const float* background;
+	const float* means3D;
+	const float* shs;
+	const float* shs_rest;
+	const float* colors_precomp;
+	const float* scales;
+	float scale_modifier;
+	const float* rotations;
+	const float* cov3D_precomp;
+	const float* viewmatrix;
+	const float* projmatrix;
+	const float* cam_pos;
+	float tan_fovx, tan_fovy;
+	const int* radii;
+	void* geometry; void* binning; void* image; void* scratch;
+	const float* dL_dpix;
+	float* dL_dmean2D; float* dL_dconic; float* dL_dopacity; float* dL_dcolor; float* dL_dmean3D;
+	float* dL_dcov3D; float* dL_dsh; float* dL_dsh_rest; float* dL_dscale; float* dL_drot;
+	float* stat_xyz_gradient_accum; float* stat_denom; float* stat_max_radii2D;
+	void* stream;
+	int debug;
+} gsr_backward_args;
+int gsr_backward_blend(const gsr_backward_args* args);
+int gsr_backward_gaussians(const gsr_backward_args* args, int first, int count, int out_row0);
 
 /*
  * View-parallel SH gradient (no reference counterpart; the reference is single-view, single-GPU).
@@ -273,17 +328,18 @@ int gsr_mark_visible(int P, const float* means3D, const float* viewmatrix, const
 uint32_t gsr_get_higher_msb(uint32_t n);
 
 /*
- * Per-kernel timing hook for benchmarks: when `events_out` is non-NULL in gsr_profile_begin(),
- * the next forward/backward calls on this thread record HIP events around each kernel on the
- * caller's stream; gsr_profile_end() synchronises and returns (name, milliseconds) pairs.
- * Not part of the reference surface.
+ * Per-kernel timing hook for benchmarks, per stream: between gsr_profile_begin(stream) and
+ * gsr_profile_end(stream, ...) every library call that is given THIS stream records HIP events around each
+ * of its stages (from whatever host thread it is made: PyTorch runs backward on its own thread);
+ * gsr_profile_end() synchronises and returns (name, milliseconds) pairs.  Calls on other streams are not
+ * recorded and pay nothing.  Not part of the reference surface.
  */
 typedef struct { const char* name; float ms; } gsr_kernel_time;
-int gsr_profile_begin(void);
+int gsr_profile_begin(void* stream);
 /* Same, recording only the stage called `stage` ("render_backward", "sort", ...): two event records per
  * step instead of two per stage, for timed regions (each record costs ~5 us of queue drain on the GPU). */
-int gsr_profile_begin_only(const char* stage);
-int gsr_profile_end(gsr_kernel_time* out, int capacity);
+int gsr_profile_begin_only(void* stream, const char* stage);
+int gsr_profile_end(void* stream, gsr_kernel_time* out, int capacity);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,209 @@
+"""GPU: properties of the C-ABI boundary itself -- caller's stream, re-entrancy from several host
+threads, optional radii, the exactness of the band culling, and the N > 1 launcher of bench.py on one GPU."""
+import ctypes
+import json
+import os
+import subprocess
+import sys
+import threading
+
+import numpy as np
+import pytest
+import torch
+
+import gsr_scene
+import util
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+
+
+def _direct(scene, cam, D, dpix, dev, **kw):
+    """forward + backward through the binding (no autograd): every tensor the reference's extension returns."""
+    from diff_gaussian_rasterization import _C
+    st = util.hip_settings(scene, cam, D, dev)
+    e = torch.empty(0, device=dev)
+    t = {k: getattr(scene, k).to(dev) for k in ("means3D", "shs", "opacities", "scales", "rotations")}
+    R, color, radii, geom, binning, img = _C.rasterize_gaussians(
+        st.bg, t["means3D"], e, t["opacities"], t["scales"], t["rotations"], 1.0, e, st.viewmatrix, st.projmatrix, st.tanfovx,
+        st.tanfovy, st.image_height, st.image_width, t["shs"], D, st.campos, False, False)
+    grads = _C.rasterize_gaussians_backward(
+        st.bg, t["means3D"], radii, e, t["scales"], t["rotations"], 1.0, e, st.viewmatrix, st.projmatrix, st.tanfovx, st.tanfovy,
+        dpix, t["shs"], D, st.campos, geom, R, binning, img, False, **kw)
+    return (color, radii) + tuple(grads)
+
+
+def _same(a, b):
+    for x, y in zip(a, b):
+        if x is None or y is None:
+            assert x is None and y is None
+        else:
+            assert torch.equal(x, y)
+
+
+def test_non_default_stream_gives_identical_results():
+    """All device work goes to the caller's stream (torch.cuda.current_stream): a side stream must give the same
+    bits as the default stream, with no implicit use of stream 0."""
+    _need_gpu()
+    dev = torch.device("cuda:0")
+    scene = gsr_scene.make_scene(9000, -3.0, sh_degree=3, seed=41)
+    cam = gsr_scene.ring_camera(320, 200, 1, 8)
+    dpix = torch.randn(3, 200, 320, generator=torch.Generator().manual_seed(8)).to(dev)
+    ref = _direct(scene, cam, 3, dpix, dev)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream(dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        got = _direct(scene, cam, 3, dpix, dev)
+        # autograd surface on the side stream too
+        from diff_gaussian_rasterization import GaussianRasterizer
+        p = {k: getattr(scene, k).to(dev).clone().requires_grad_(True) for k in ("means3D", "shs", "opacities", "scales", "rotations")}
+        m2 = torch.zeros_like(p["means3D"], requires_grad=True)
+        color, _ = GaussianRasterizer(util.hip_settings(scene, cam, 3, dev))(means2D=m2, **p)
+        color.backward(dpix)
+    side.synchronize()
+    _same(ref, got)
+    assert torch.equal(color, ref[0]) and torch.equal(p["means3D"].grad, ref[5]) and torch.equal(p["shs"].grad, ref[7])
+
+
+def test_two_host_threads_call_the_library_concurrently():
+    """Re-entrancy: two Python threads, each on its own stream, run forward + backward of different scenes
+    through the C ABI at the same time (ctypes releases the GIL during the calls); every iteration must reproduce the
+    serial result bit for bit.  One of the threads also records per-kernel events: profiling state is per stream."""
+    _need_gpu()
+    from diff_gaussian_rasterization import _C
+    dev = torch.device("cuda:0")
+    jobs = []
+    for seed, P, W, H in ((1, 12000, 400, 240), (2, 5000, 256, 144)):
+        scene = gsr_scene.make_scene(P, -3.0, sh_degree=3, seed=seed)
+        cam = gsr_scene.ring_camera(W, H, seed, 8)
+        dpix = torch.randn(3, H, W, generator=torch.Generator().manual_seed(seed)).to(dev)
+        jobs.append((scene, cam, dpix, _direct(scene, cam, 3, dpix, dev)))
+    torch.cuda.synchronize()
+    errors, recorded = [], {}
+
+    def work(k):
+        try:
+            scene, cam, dpix, ref = jobs[k]
+            s = torch.cuda.Stream(dev)
+            with torch.cuda.stream(s):
+                if k == 0:
+                    _C.profile_begin(device=dev)
+                for _ in range(6):
+                    got = _direct(scene, cam, 3, dpix, dev)
+                    s.synchronize()
+                    _same(ref, got)
+                if k == 0:
+                    recorded["names"] = [n for n, _ in _C.profile_end(1024, device=dev)]
+        except Exception as ex:  # noqa: BLE001
+            errors.append(repr(ex))
+
+    th = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors
+    # thread 0's recorder saw exactly its own 6 steps (its stream), none of thread 1's
+    assert recorded["names"].count("render_backward") == 6 and recorded["names"].count("preprocess") == 6
+
+
+def test_radii_may_be_null_like_the_reference_default():
+    """`int* radii = nullptr` (cuda_rasterizer/rasterizer.h:52,69): forward and backward accept a NULL radii."""
+    _need_gpu()
+    from diff_gaussian_rasterization import _C
+    L = _C.lib()
+    dev = torch.device("cuda:0")
+    scene = gsr_scene.make_scene(4000, -3.0, sh_degree=3, seed=12)
+    cam = gsr_scene.ring_camera(200, 120, 3, 8, radius=2.5)   # part of the scene is behind the camera
+    st = util.hip_settings(scene, cam, 3, dev)
+    dpix = torch.randn(3, 120, 200, generator=torch.Generator().manual_seed(3)).to(dev)
+    ref = _direct(scene, cam, 3, dpix, dev)
+    P, W, H = 4000, 200, 120
+    t = {k: getattr(scene, k).to(dev).contiguous() for k in ("means3D", "shs", "opacities", "scales", "rotations")}
+    byte = dict(dtype=torch.uint8, device=dev)
+    geom = torch.empty(L.gsr_geometry_bytes(P), **byte)
+    img = torch.empty(L.gsr_image_bytes(W, H), **byte)
+    color = torch.empty(3, H, W, device=dev)
+    R = ctypes.c_int64(0)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    ptr = lambda x: x.data_ptr()
+    _C._check(L.gsr_forward_preprocess(P, 3, 16, W, H, ptr(t["means3D"]), ptr(t["shs"]), None, ptr(t["opacities"]), ptr(t["scales"]), 1.0,
+                                       ptr(t["rotations"]), None, ptr(st.viewmatrix), ptr(st.projmatrix), ptr(st.campos), st.tanfovx,
+                                       st.tanfovy, 0, None, ptr(geom), ctypes.byref(R), stream, 0))
+    R = int(R.value)
+    binning = torch.empty(L.gsr_binning_bytes(P, R, W, H), **byte)
+    _C._check(L.gsr_forward_render(P, R, W, H, ptr(st.bg), None, ptr(geom), ptr(binning), ptr(img), ptr(color), stream, 0))
+    assert torch.equal(color, ref[0])
+    f32 = dict(dtype=torch.float32, device=dev)
+    g = dict(m2=torch.empty(P, 3, **f32), op=torch.empty(P, 1, **f32), m3=torch.empty(P, 3, **f32), sh=torch.empty(P, 16, 3, **f32),
+             sc=torch.empty(P, 3, **f32), rot=torch.empty(P, 4, **f32))
+    scratch = torch.empty(L.gsr_backward_scratch_bytes(P, R), **byte)
+    _C._check(L.gsr_backward(P, 3, 16, R, W, H, ptr(st.bg), ptr(t["means3D"]), ptr(t["shs"]), None, ptr(t["scales"]), 1.0, ptr(t["rotations"]),
+                             None, ptr(st.viewmatrix), ptr(st.projmatrix), ptr(st.campos), st.tanfovx, st.tanfovy, None, ptr(geom),
+                             ptr(binning), ptr(img), ptr(scratch), ptr(dpix), ptr(g["m2"]), None, ptr(g["op"]), None, ptr(g["m3"]), None,
+                             ptr(g["sh"]), ptr(g["sc"]), ptr(g["rot"]), stream, 0))
+    torch.cuda.synchronize()
+    # tuple of _direct: color, radii, dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations
+    for got, want in ((g["m2"], ref[2]), (g["op"], ref[4]), (g["m3"], ref[5]), (g["sh"], ref[7]), (g["sc"], ref[8]), (g["rot"], ref[9])):
+        assert torch.equal(got, want)
+
+
+@pytest.mark.parametrize("case", ["fuzz", "C2"])
+def test_band_culling_changes_nothing(case):
+    """The staging lanes drop (instance, 16x4-pixel band) pairs that cannot reach alpha = 1/255 (render_common.h
+    gsr_tile_band_mask).  GSR_NO_CULL=1 evaluates every pair like the reference: images, n_contrib and every gradient
+    must be bit-identical with and without the culling -- the direct check of its safety margin."""
+    _need_gpu()
+    dev = torch.device("cuda:0")
+    if case == "C2":
+        scene, cam, D = gsr_scene.make_config("C2")
+        runs = [(scene, cam, D)]
+    else:
+        runs = []
+        for seed in range(6):   # the randomised configurations of test_fuzz_gpu: cameras inside the cloud, odd sizes, big splats
+            rng = np.random.default_rng(100 + seed)
+            P = int(rng.integers(500, 6000))
+            W, H = int(rng.integers(40, 400)), int(rng.integers(30, 260))
+            D = int(rng.integers(0, 4))
+            mu = float(rng.uniform(-3.5, -1.0))
+            scene = gsr_scene.make_scene(P, mu, sh_degree=D, seed=seed)
+            cam = gsr_scene.ring_camera(W, H, int(rng.integers(0, 8)), 8, radius=float(rng.uniform(0.3, 4.5)))
+            runs.append((scene, cam, D))
+    prev = os.environ.get("GSR_NO_CULL")
+    try:
+        for scene, cam, D in runs:
+            dpix = torch.randn(3, cam.image_height, cam.image_width, generator=torch.Generator().manual_seed(1)).to(dev)
+            os.environ["GSR_NO_CULL"] = "0"
+            a = _direct(scene, cam, D, dpix, dev)
+            os.environ["GSR_NO_CULL"] = "1"
+            b = _direct(scene, cam, D, dpix, dev)
+            _same(a, b)
+    finally:
+        if prev is None:
+            os.environ.pop("GSR_NO_CULL", None)
+        else:
+            os.environ["GSR_NO_CULL"] = prev
+
+
+def test_bench_gpus_2_on_one_gpu_over_gloo():
+    """`python bench.py --gpus 2` with no launcher starts two ranks itself; here both share the one GPU of the box and
+    exchange over gloo (GSR_BENCH_BACKEND=gloo) -- the rehearsal of the view-parallel step (rasterize_view_parallel,
+    both exchange modes) that is possible without a second GPU."""
+    _need_gpu()
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["GSR_BENCH_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "C1", "--steps", "3", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["views_per_step"] == 2
+    assert d["alt_exchange"]["mode"] == "allreduce" and d["alt_exchange"]["value"] > 0
+    assert d["data"] == "synthetic" and d["kernels"]["render_backward"]["ms"] > 0

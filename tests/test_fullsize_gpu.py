@@ -18,6 +18,29 @@ def _need_gpu():
         pytest.skip("no GPU")
 
 
+NAMES = ["dL_dmeans3D", "dL_dmeans2D", "dL_dopacity", "dL_dsh", "dL_dscales", "dL_drotations"]
+
+
+def exclusion_figures(name, scene, cam, D, o, h):
+    """What the parity bars leave out, printed next to them: the fragile-pixel fraction, the image error over ALL pixels
+    (fragile ones included), and the gradient error when the upstream gradient is NOT zeroed on the fragile pixels.
+    A fragile pixel is one where a 1-ulp difference of exp() legitimately flips alpha < 1/255 or T(1-alpha) < 1e-4; the
+    pixel then moves by up to alpha*T (~4e-3), which is why these are reported, and bounded loosely, not held to 1e-5."""
+    ok = o["fragile"] == 0
+    diff = np.abs(h["color"].reshape(3, -1) - o["color"].reshape(3, -1))
+    frag = float(1.0 - ok.mean())
+    full_max, ok_max = float(diff.max()), float(diff[:, ok].max())
+    g = torch.Generator().manual_seed(1)
+    dpix = torch.randn(3, cam.image_height, cam.image_width, generator=g)   # unmasked
+    hu = util.hip_forward_backward(scene, cam, D, dpix)
+    og = util.oracle.backward(o, dpix.numpy())
+    rel = {k: float(np.abs(hu["grads"][k].astype(np.float64) - og[k]).max() / max(np.abs(og[k]).max(), 1e-30)) for k in NAMES}
+    print(f"[{name}] fragile pixels {frag:.3e} of the image; image max-abs error: all pixels {full_max:.3e}, non-fragile {ok_max:.3e}; "
+          "gradient error with UNMASKED dL/dpix (max-abs / max|g|): " + ", ".join(f"{k} {v:.2e}" for k, v in rel.items()))
+    assert frag < 5e-3 and full_max < 2e-2 and max(rel.values()) < 2e-3
+    return frag, full_max, rel
+
+
 def test_c2_full_parity_with_oracle():
     _need_gpu()
     scene, cam, D = gsr_scene.make_config("C2")
@@ -25,7 +48,31 @@ def test_c2_full_parity_with_oracle():
     dpix = util.fragile_free_dpix(o, cam)
     h = util.hip_forward_backward(scene, cam, D, dpix)
     check_forward(h, o, cam)
-    check_grads(h, o, dpix, ["dL_dmeans3D", "dL_dmeans2D", "dL_dopacity", "dL_dsh", "dL_dscales", "dL_drotations"])
+    check_grads(h, o, dpix, NAMES)
+    exclusion_figures("C2", scene, cam, D, o, h)
+
+
+def test_c3_full_parity_with_oracle():
+    """The headline workload (1M Gaussians, 1980x1080, SH degree 3) against the oracle in full: every integer output
+    exact, image and gradients to the same bars as the small cases."""
+    _need_gpu()
+    scene, cam, D = gsr_scene.make_config("C3")
+    o = util.oracle_forward(scene, cam, D)
+    dpix = util.fragile_free_dpix(o, cam)
+    h = util.hip_forward_backward(scene, cam, D, dpix)
+    check_forward(h, o, cam)
+    check_grads(h, o, dpix, NAMES)
+    exclusion_figures("C3", scene, cam, D, o, h)
+
+
+def test_c5_integer_state_parity_with_oracle():
+    """6M Gaussians at 3840x2160: radii, tiles, sorted instance list, 64-bit keys, tile ranges exact; image 1e-5 and
+    n_contrib exact on the non-fragile pixels (check_forward).  Gradients at this size: properties only (below)."""
+    _need_gpu()
+    scene, cam, D = gsr_scene.make_config("C5")
+    o = util.oracle_forward(scene, cam, D)
+    h = util.hip_forward_backward(scene, cam, D, None)
+    check_forward(h, o, cam)
 
 
 def _properties(name, check_linearity=True):

@@ -107,8 +107,8 @@ def test_leaf_mode_equals_pytorch_activations_around_the_rasterizer(P, D, M, siz
 
 
 def test_leaf_mode_through_render_and_view_parallel_switch():
-    """gaussian_renderer.render(pipe.fused_activations=True) returns the reference's dict; inside
-    view_parallel.skip_sh_gradient() the feature gradients are skipped and dL/dRGB is handed over."""
+    """gaussian_renderer.render(pipe.fused_activations=True) returns the reference's dict; the two-stage C ABI in leaf
+    mode without feature gradients hands dL/dRGB over instead (view-parallel mode)."""
     _need_gpu()
     import gsr_model
     import view_parallel
@@ -132,16 +132,27 @@ def test_leaf_mode_through_render_and_view_parallel_switch():
         assert float((a - b).abs().max()) <= GRAD_RTOL * float(b.abs().max())
     assert float((res[True][3] - res[False][3]).abs().max()) <= GRAD_RTOL * float(res[False][3].abs().max())
 
-    pc = gsr_model.GaussianParams.from_activated(scene.means3D, scene.shs, scene.scales, scene.rotations, scene.opacities, device=dev)
-    r = render(cam, pc, gsr_model.pipeline_params(fused_activations=True), scene.bg.to(dev))
-    with view_parallel.skip_sh_gradient() as side:
-        r["render"].backward(dpix)
-    assert pc._features_dc.grad is None and pc._features_rest.grad is None
+    # view-parallel mode of the leaf backward: no feature gradients, dL/dRGB instead, everything else unchanged
+    import fused_params
     from diff_gaussian_rasterization import _C
-    sh_grad = _C.sh_grad_from_views(pc._xyz.detach(), cam.camera_center[None], side.dL_dRGB[None], 3, 16)
+    pc = gsr_model.GaussianParams.from_activated(scene.means3D, scene.shs, scene.scales, scene.rotations, scene.opacities, device=dev)
+    st = util.hip_settings(scene, cam, 3, dev)
+    with torch.no_grad():
+        R, color, radii, geom, binning, img, M, (xyz, fdc, frest, scaling, rotation) = fused_params.leaf_forward(
+            pc._xyz, pc._features_dc, pc._features_rest, pc._opacity, pc._scaling, pc._rotation, st)
+    P = xyz.shape[0]
+    f32 = dict(dtype=torch.float32, device=dev)
+    out = dict(dL_dmean2D=torch.empty(P, 3, **f32), dL_dmean3D=torch.empty(P, 3, **f32), dL_dopacity=torch.empty(P, 1, **f32),
+               dL_dscale=torch.empty(P, 3, **f32), dL_drot=torch.empty(P, 4, **f32), dL_dcolor=torch.empty(P, 3, **f32))
+    scratch = torch.empty(_C.lib().gsr_backward_scratch_bytes(P, R), dtype=torch.uint8, device=dev)
+    a = fused_params.leaf_backward_args(st, R, M, xyz, fdc, frest, scaling, rotation, radii, geom, binning, img, scratch, dpix)
+    _C.set_backward_outputs(a, **out)
+    _C.backward_blend(a)
+    _C.backward_gaussians(a, 0, P, 0)
+    sh_grad = _C.sh_grad_from_views(xyz, cam.camera_center[None], out["dL_dcolor"][None], 3, 16)
     want = torch.cat((res[True][2][1], res[True][2][2]), dim=1)
     assert torch.equal(sh_grad, want)
-    assert torch.equal(pc._xyz.grad, res[True][2][0])
+    assert torch.equal(out["dL_dmean3D"], res[True][2][0])
 
 
 def _adam_problem(dev, P, seed):

@@ -43,6 +43,65 @@ def test_camera_matrices_match_reference_graphics_utils():
         np.testing.assert_array_equal(p, g["proj"][k])
 
 
+def test_camera_composition_matches_reference_camera_class():
+    """scene/cameras.py:57-61 (world_view_transform, projection, full_proj_transform, camera_center), produced by the
+    reference's own Camera class: gsr_scene.make_camera composes the same four tensors bit for bit."""
+    g = np.load(os.path.join(GOLD, "camera_class_golden.npz"))
+    for k in range(g["R"].shape[0]):
+        fovx, fovy = float(g["fovx"][k]), float(g["fovy"][k])
+        wvt = torch.tensor(gsr_scene.world_to_view(g["R"][k], g["T"][k])).transpose(0, 1)
+        proj = gsr_scene.projection_matrix(0.01, 100.0, fovx, fovy).transpose(0, 1)
+        np.testing.assert_array_equal(wvt.numpy(), g["world_view_transform"][k])
+        np.testing.assert_array_equal(proj.numpy(), g["projection_matrix"][k])
+        full = wvt.unsqueeze(0).bmm(proj.unsqueeze(0)).squeeze(0)
+        np.testing.assert_array_equal(full.numpy(), g["full_proj_transform"][k])
+        np.testing.assert_array_equal(wvt.inverse()[3, :3].numpy(), g["camera_center"][k])
+    # make_camera itself (tanfovy is tied to the aspect ratio there): same composition on its own FoV pair
+    cam = gsr_scene.make_camera(64, 48, fovx=float(g["fovx"][0]), R=g["R"][0], T=g["T"][0])
+    np.testing.assert_array_equal(cam.world_view_transform.numpy(), g["world_view_transform"][0])
+    proj = gsr_scene.projection_matrix(0.01, 100.0, cam.FoVx, cam.FoVy).transpose(0, 1)
+    np.testing.assert_array_equal(cam.full_proj_transform.numpy(), cam.world_view_transform.unsqueeze(0).bmm(proj.unsqueeze(0)).squeeze(0).numpy())
+    np.testing.assert_array_equal(cam.camera_center.numpy(), g["camera_center"][0])
+
+
+def test_cov3d_matches_reference_general_utils():
+    """computeCov3D (forward.cu:146-180) as restated by the oracle, and the product's Python alternate
+    (gsr_model.build_covariance_from_scaling_rotation, the compute_cov3D_python branch), against the covariance the
+    reference's own utils/general_utils.py functions produce (scene/gaussian_model.py:32-37), unit quaternions."""
+    import gsr_model
+    g = np.load(os.path.join(GOLD, "cov3d_golden.npz"))
+    scaling, q = torch.from_numpy(g["scaling"]), torch.from_numpy(g["rotation_unit"])
+    n = scaling.shape[0]
+    R = gsr_model.build_rotation(torch.from_numpy(g["rotation_raw"])).numpy()
+    np.testing.assert_allclose(R, g["R_of_raw"], rtol=0, atol=1e-6)
+    for mod in (1.0, 1.7):
+        want = g[f"cov_mod{mod}"]
+        scale_of = np.abs(want).max(axis=1, keepdims=True)
+        got = gsr_model.build_covariance_from_scaling_rotation(scaling, mod, q).numpy()
+        assert np.abs(got - want).max() <= 0 or (np.abs(got - want) / scale_of).max() < 2e-6
+        # the oracle's computeCov3D through its preprocess (every Gaussian in front of the camera)
+        means = np.zeros((n, 3), np.float32)
+        means[:, 0] = np.linspace(-0.5, 0.5, n)
+        cam = gsr_scene.make_camera(64, 48)
+        o = oracle.forward(means, np.full((n, 1), 0.5, np.float32), cam.world_view_transform.numpy(), cam.full_proj_transform.numpy(),
+                           cam.camera_center.numpy(), np.zeros(3, np.float32), 64, 48, cam.tanfovx, cam.tanfovy, 0,
+                           shs=np.zeros((n, 1, 3), np.float32), scales=g["scaling"], rotations=g["rotation_unit"], scale_modifier=mod)
+        assert (np.abs(o["cov3D"] - want) / scale_of).max() < 2e-6
+
+
+def test_product_eval_sh_matches_reference_eval_sh():
+    """gsr_model.eval_sh (the convert_SHs_python alternate of the product) against the reference's eval_sh outputs."""
+    import gsr_model
+    g = np.load(os.path.join(GOLD, "sh_golden.npz"))
+    pos, campos, shs = torch.from_numpy(g["pos"]), torch.from_numpy(g["campos"]), torch.from_numpy(g["shs"])
+    d = pos - campos
+    d = d / d.norm(dim=1, keepdim=True)
+    for deg in range(4):
+        raw = gsr_model.eval_sh(deg, shs.transpose(1, 2), d) + 0.5
+        np.testing.assert_allclose(raw.numpy(), g[f"raw_deg{deg}"], rtol=0, atol=2e-6)
+        np.testing.assert_allclose(torch.clamp_min(raw, 0).numpy(), g[f"rgb_deg{deg}"], rtol=0, atol=2e-6)
+
+
 def test_get_higher_msb():
     # rasterizer_impl.cu:37-52; values quoted in SURVEY.md 8a-10: bit = 9 / 14 / 14 / 15 for C1 / C2 / C3 / C5
     assert oracle.get_higher_msb(256) == 9

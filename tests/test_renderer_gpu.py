@@ -137,8 +137,8 @@ def test_giant_elongated_splats_are_never_culled_wrongly():
 
 
 def test_view_parallel_compact_sh_gradient_equals_sum_of_per_view_gradients():
-    """view_parallel.exchange_sh_gradient: rebuilding the summed SH gradient from 3 floats per Gaussian
-    per view gives exactly the fixed-order sum of the per-view dL_dsh the rasterizer itself produces,
+    """Rebuilding the summed SH gradient from 3 floats per Gaussian per view (skip_sh mode of the backward +
+    gsr_sh_grad_from_views) gives exactly the fixed-order sum of the per-view dL_dsh the rasterizer itself produces,
     and leaves every other gradient untouched."""
     _need_gpu()
     import view_parallel
@@ -151,35 +151,144 @@ def test_view_parallel_compact_sh_gradient_equals_sum_of_per_view_gradients():
         dpix = torch.randn(3, 120, 200, generator=g).to(dev)
 
         def run(cam, skip):
+            """plain autograd run, or a direct call of the binding's backward with skip_sh=True on the same state"""
             p = {k: getattr(scene, k).to(dev).clone().requires_grad_(True) for k in ("means3D", "shs", "opacities", "scales", "rotations")}
             m2 = torch.zeros_like(p["means3D"], requires_grad=True)
-            color, _ = GaussianRasterizer(util.hip_settings(scene, cam, D, dev))(means2D=m2, **p)
-            if skip:
-                with view_parallel.skip_sh_gradient() as side:
-                    color.backward(dpix)
-                return p, side.dL_dRGB
-            color.backward(dpix)
-            return p, None
+            st = util.hip_settings(scene, cam, D, dev)
+            if not skip:
+                color, _ = GaussianRasterizer(st)(means2D=m2, **p)
+                color.backward(dpix)
+                return {k: v.grad for k, v in p.items()}, None
+            e = torch.empty(0, device=dev)
+            R, color, radii, geom, binning, img = _C.rasterize_gaussians(
+                st.bg, p["means3D"].detach(), e, p["opacities"].detach(), p["scales"].detach(), p["rotations"].detach(), 1.0, e,
+                st.viewmatrix, st.projmatrix, st.tanfovx, st.tanfovy, st.image_height, st.image_width, p["shs"].detach(), D,
+                st.campos, False, False)
+            d2, drgb, dop, d3, dcov, dsh, dsc, drot = _C.rasterize_gaussians_backward(
+                st.bg, p["means3D"].detach(), radii, e, p["scales"].detach(), p["rotations"].detach(), 1.0, e, st.viewmatrix,
+                st.projmatrix, st.tanfovx, st.tanfovy, dpix, p["shs"].detach(), D, st.campos, geom, R, binning, img, False,
+                lean=True, skip_sh=True)
+            assert dsh is None
+            return dict(means3D=d3, opacities=dop, scales=dsc, rotations=drot), drgb
 
         ref = [run(c, False)[0] for c in cams]
         skp = [run(c, True) for c in cams]
-        for (p_ref, (p_skip, rgb)) in zip(ref, skp):
-            assert p_skip["shs"].grad is None and rgb is not None and rgb.shape == (6000, 3)
+        for (g_ref, (g_skip, rgb)) in zip(ref, skp):
+            assert rgb is not None and rgb.shape == (6000, 3)
             for k in ("means3D", "opacities", "scales", "rotations"):
-                assert torch.equal(p_ref[k].grad, p_skip[k].grad), k
-        want = (ref[0]["shs"].grad + ref[1]["shs"].grad) + ref[2]["shs"].grad
+                assert torch.equal(g_ref[k], g_skip[k]), k
+        want = (ref[0]["shs"] + ref[1]["shs"]) + ref[2]["shs"]
         rgb_all = torch.stack([s[1] for s in skp])
         cam_all = torch.stack([c.camera_center for c in cams]).to(dev)
         got = _C.sh_grad_from_views(scene.means3D.to(dev), cam_all, rgb_all, D, M)
         assert got.shape == (6000, M, 3)
         assert torch.equal(got, want), float((got - want).abs().max())
-        # views handed over as strided blocks with a trailer row (the layout ShExchange all-gathers): consumed in place
+        # views handed over as strided blocks with a trailer row (the layout the exchange all-gathers): consumed in place
         blocks = torch.full((3, 6001, 3), float("nan"), device=dev)
         blocks[:, :6000] = rgb_all
         assert torch.equal(_C.sh_grad_from_views(scene.means3D.to(dev), cam_all, blocks[:, :6000, :], D, M), want)
         # single-process form of the exchange (world size 1)
         one = view_parallel.exchange_sh_gradient(scene.means3D.to(dev), cam_all[0], rgb_all[0], D, M)
-        assert torch.equal(one, ref[0]["shs"].grad)
+        assert torch.equal(one, ref[0]["shs"])
+
+
+@pytest.mark.parametrize("sh_mode", ["compact", "allreduce"])
+def test_view_parallel_rasterizer_world1_equals_plain_rasterizer(sh_mode):
+    """view_parallel.rasterize_view_parallel with a single rank: the part-by-part backward with the exchange buffers
+    (two parts, outputs written straight into the buckets) returns bit for bit what the drop-in rasterizer returns."""
+    _need_gpu()
+    import view_parallel
+    from diff_gaussian_rasterization import GaussianRasterizer
+    dev = torch.device("cuda:0")
+    P = 7013
+    scene = gsr_scene.make_scene(P, -3.0, sh_degree=3, seed=77)
+    cam = gsr_scene.ring_camera(240, 136, 2, 8)
+    st = util.hip_settings(scene, cam, 3, dev)
+    dpix = torch.randn(3, 136, 240, generator=torch.Generator().manual_seed(3)).to(dev)
+    names = ("means3D", "shs", "opacities", "scales", "rotations")
+
+    def leaves():
+        return {k: getattr(scene, k).to(dev).clone().requires_grad_(True) for k in names}
+    p = leaves()
+    m2 = torch.zeros_like(p["means3D"], requires_grad=True)
+    color, radii = GaussianRasterizer(st)(means2D=m2, **p)
+    color.backward(dpix)
+    ex = view_parallel.GradientExchange(P, 16, dev, sh_mode=sh_mode, parts=2)
+    assert len(ex.ranges) == 2 and ex.ranges[0][1] % 256 == 0 and sum(c for _, c in ex.ranges) == P
+    for _ in range(2):  # the exchange object is reused step after step
+        q = leaves()
+        n2 = torch.zeros_like(q["means3D"], requires_grad=True)
+        color2, radii2 = view_parallel.rasterize_view_parallel(q["means3D"], n2, q["shs"], q["opacities"], q["scales"], q["rotations"], st, ex)
+        color2.backward(dpix)
+        assert torch.equal(color, color2) and torch.equal(radii, radii2)
+        assert torch.equal(m2.grad, n2.grad)
+        for k in names:
+            assert torch.equal(p[k].grad, q[k].grad), k
+
+
+def test_densification_statistics_from_the_backward_epilogue():
+    """the backward's per-Gaussian kernel accumulates, per view, what train.py:157-159 and
+    scene/gaussian_model.py:599-602 compute from (viewspace_points.grad, radii) -- checked against that sequential
+    bookkeeping over three views, for the drop-in rasterizer, the leaf-mode one and the view-parallel one."""
+    _need_gpu()
+    import gsr_model
+    import view_parallel
+    from diff_gaussian_rasterization import GaussianRasterizer
+    from fused_params import rasterize_leaf_gaussians
+    dev = torch.device("cuda:0")
+    P = 5000
+    scene = gsr_scene.make_scene(P, -3.0, sh_degree=3, seed=31)
+    cams = [gsr_scene.ring_camera(200, 120, k, 8, radius=2.5) for k in (0, 2, 5)]   # some Gaussians behind the camera
+    dpix = torch.randn(3, 120, 200, generator=torch.Generator().manual_seed(6)).to(dev)
+    names = ("means3D", "shs", "opacities", "scales", "rotations")
+    # the reference's bookkeeping
+    max_radii2D, accum, denom = torch.zeros(P, device=dev), torch.zeros(P, 1, device=dev), torch.zeros(P, 1, device=dev)
+    for cam in cams:
+        p = {k: getattr(scene, k).to(dev).clone().requires_grad_(True) for k in names}
+        m2 = torch.zeros_like(p["means3D"], requires_grad=True)
+        color, radii = GaussianRasterizer(util.hip_settings(scene, cam, 3, dev))(means2D=m2, **p)
+        color.backward(dpix)
+        vis = radii > 0
+        assert 0 < int(vis.sum()) < P
+        max_radii2D[vis] = torch.max(max_radii2D[vis], radii[vis].float())                  # train.py:157
+        accum[vis] += torch.norm(m2.grad[vis, :2], dim=-1, keepdim=True)                     # gaussian_model.py:600
+        denom[vis] += 1                                                                      # gaussian_model.py:601
+
+    def check(stats):
+        stats.sync()
+        assert torch.equal(stats.max_radii2D, max_radii2D)
+        assert torch.equal(stats.denom, denom)
+        assert torch.allclose(stats.xyz_gradient_accum, accum, rtol=2e-6, atol=0)
+
+    stats = view_parallel.DensificationStats(P, dev)
+    for cam in cams:
+        p = {k: getattr(scene, k).to(dev).clone().requires_grad_(True) for k in names}
+        m2 = torch.zeros_like(p["means3D"], requires_grad=True)
+        color, _ = GaussianRasterizer(util.hip_settings(scene, cam, 3, dev), densify_stats=stats.kernel_tensors())(means2D=m2, **p)
+        color.backward(dpix)
+    check(stats)
+
+    stats = view_parallel.DensificationStats(P, dev)
+    ex = view_parallel.GradientExchange(P, 16, dev, parts=3)
+    for cam in cams:
+        p = {k: getattr(scene, k).to(dev).clone().requires_grad_(True) for k in names}
+        m2 = torch.zeros_like(p["means3D"], requires_grad=True)
+        color, _ = view_parallel.rasterize_view_parallel(p["means3D"], m2, p["shs"], p["opacities"], p["scales"], p["rotations"],
+                                                          util.hip_settings(scene, cam, 3, dev), ex, stats.kernel_tensors())
+        color.backward(dpix)
+    check(stats)
+
+    stats = view_parallel.DensificationStats(P, dev)
+    for cam in cams:
+        pc = gsr_model.GaussianParams.from_activated(scene.means3D, scene.shs, scene.scales, scene.rotations, scene.opacities, device=dev)
+        m2 = torch.zeros_like(pc._xyz, requires_grad=True)
+        color, _ = rasterize_leaf_gaussians(pc._xyz, m2, pc._features_dc, pc._features_rest, pc._opacity, pc._scaling, pc._rotation,
+                                            util.hip_settings(scene, cam, 3, dev), stats.kernel_tensors())
+        color.backward(dpix)
+    stats.sync()
+    assert torch.equal(stats.max_radii2D, max_radii2D) and torch.equal(stats.denom, denom)
+    # leaf mode starts from log / logit / raw leaves whose activations reproduce the scene only to fp32 rounding
+    assert float((stats.xyz_gradient_accum - accum).abs().max()) <= 1e-4 * float(accum.max())
 
 
 def test_backward_twice_over_the_same_forward_state():

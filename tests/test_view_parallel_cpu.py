@@ -66,7 +66,8 @@ def _stats_worker(rank, world, port, P):
         stats = view_parallel.DensificationStats(P)
         for step in range(2):
             grad, radii = view(rank + world * step)
-            stats.update(grad, radii)
+            stats.update(grad, radii)   # local accumulation (on the GPU: the backward kernel's epilogue does this)
+        stats.sync()                    # ONE MAX + ONE SUM all-reduce, whenever the statistics are read
         # the reference's bookkeeping applied once per view, sequentially (train.py:157-159, gaussian_model.py:599-602)
         max_radii2D, accum, denom = torch.zeros(P), torch.zeros(P, 1), torch.zeros(P, 1)
         for v in range(2 * world):
@@ -94,9 +95,13 @@ def _exchange_worker(rank, world, port, P):
         from diff_gaussian_rasterization import _C
         seen = {}
 
-        def stub(means3D, cam_all, rgb_all, degree, M):  # stands in for the HIP kernel: records what it is handed
+        def stub(means3D, cam_all, rgb_all, degree, M, out=None):  # stands in for the HIP kernel: records what it is handed
             seen["cam"], seen["rgb"], seen["D"], seen["M"] = cam_all.clone(), rgb_all.clone(), degree, M
-            return rgb_all.sum(0)[:, None, :].expand(-1, M, -1).contiguous()
+            r = rgb_all.sum(0)[:, None, :].expand(-1, M, -1).contiguous()
+            if out is not None:
+                out.copy_(r)
+                return out
+            return r
         orig = _C.sh_grad_from_views
         _C.sh_grad_from_views = stub
         try:
@@ -104,16 +109,80 @@ def _exchange_worker(rank, world, port, P):
             rgb = torch.full((P, 3), float(rank + 1)) + torch.arange(P)[:, None]
             cam = torch.tensor([rank, 10.0 * rank, -4.0])
             out = view_parallel.exchange_sh_gradient(means, cam, rgb, 2, 9)
+            assert seen["rgb"].shape == (world, P, 3) and seen["cam"].shape == (world, 3) and (seen["D"], seen["M"]) == (2, 9)
+            for r in range(world):  # every rank sees every view, in rank order
+                assert torch.equal(seen["rgb"][r], torch.full((P, 3), float(r + 1)) + torch.arange(P)[:, None])
+                assert torch.equal(seen["cam"][r], torch.tensor([r, 10.0 * r, -4.0]))
+            assert out.shape == (P, 9, 3)
+
+            # the pipelined per-part exchange: what a rank's backward kernel would write into the part buffers
+            P2, M = 1500, 16
+            g = torch.Generator().manual_seed(7)
+            full = {n: torch.randn(P2, w, generator=g) for n, w in view_parallel._SMALL}   # same on every rank
+            rgb_full = torch.randn(P2, 3, generator=g)
+            sh_full = torch.randn(P2, M, 3, generator=g)
+            tot = sum(range(1, world + 1))
+            for mode in ("compact", "allreduce"):
+                ex = view_parallel.GradientExchange(P2, M, "cpu", sh_mode=mode, parts=3)
+                assert [f % 256 for f, _ in ex.ranges] == [0] * len(ex.ranges) and sum(c for _, c in ex.ranges) == P2
+                assert len(ex.ranges) == 3
+                for _ in range(2):   # buffers are reused step after step
+                    ex.begin_step()
+                    for k, (first, c) in enumerate(ex.ranges):
+                        for n, sec in ex.sections(k).items():
+                            sec.copy_(full[n][first:first + c] * (rank + 1))
+                        if mode == "compact":
+                            ex.rgb[k][:c] = rgb_full[first:first + c] * (rank + 1)
+                        else:
+                            ex.dsh[first:first + c] = sh_full[first:first + c] * (rank + 1)
+                        ex.submit(k, torch.tensor([float(rank), 0.0, 1.0]))
+                    res = ex.finish(torch.zeros(P2, 3), 3)
+                    for n, _ in view_parallel._SMALL:
+                        assert res[n].shape == full[n].shape and torch.allclose(res[n], full[n] * tot), n
+                    if mode == "compact":   # the stub summed the gathered views: every rank's rows, rank order, camera trailer
+                        want = (rgb_full * tot)[:, None, :].expand(-1, M, -1)
+                        assert torch.allclose(res["dL_dsh"], want)
+                        assert torch.equal(seen["cam"], torch.tensor([[float(r), 0.0, 1.0] for r in range(world)]))
+                    else:
+                        assert torch.allclose(res["dL_dsh"], sh_full * tot)
         finally:
             _C.sh_grad_from_views = orig
-        assert seen["rgb"].shape == (world, P, 3) and seen["cam"].shape == (world, 3) and (seen["D"], seen["M"]) == (2, 9)
-        for r in range(world):  # every rank sees every view, in rank order
-            assert torch.equal(seen["rgb"][r], torch.full((P, 3), float(r + 1)) + torch.arange(P)[:, None])
-            assert torch.equal(seen["cam"][r], torch.tensor([r, 10.0 * r, -4.0]))
-        assert out.shape == (P, 9, 3)
+
+        # GradientBucket: average + async is pre-scaled, not silently skipped
+        p = torch.zeros(5, requires_grad=True)
+        p.grad = torch.full((5,), float(rank + 1))
+        b = view_parallel.GradientBucket([p])
+        w = b.all_reduce(average=True, async_op=True)
+        w.wait()
+        assert torch.allclose(p.grad, torch.full((5,), sum(range(1, world + 1)) / world))
     finally:
         dist.destroy_process_group()
 
 
 def test_sh_gradient_exchange_wiring_gloo_world2():
     mp.spawn(_exchange_worker, args=(2, _free_port(), 37), nprocs=2, join=True)
+
+
+def test_bench_gpus_2_starts_two_ranks_without_a_launcher():
+    """`python bench.py --gpus 2` (no torchrun, no RANK in the environment) must start two ranks itself.  Here, without
+    a GPU, through the plumbing rehearsal mode: process group over gloo, both exchange modes, the JSON contract."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["GSR_BENCH_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--config", "C1", "--steps", "3", "--warmup", "1",
+                        "--dry-run"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak"
+    assert d["alt_exchange"]["mode"] == "allreduce" and d["step_ms"]["n"] == 3
+    assert "dry-run" in d["data"]
+    # a launcher that started a different number of ranks than --gpus says is an error, not a silent n_gpus
+    env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run"], env=env2, capture_output=True,
+                        text=True, timeout=120)
+    assert r2.returncode != 0 and "WORLD_SIZE=1" in (r2.stderr + r2.stdout)

@@ -70,21 +70,20 @@ def hip_forward_backward(scene, cam, D, dpix=None, dev="cuda:0", colors_precomp=
         raw = {}
         orig_b = _C.rasterize_gaussians_backward
 
-        def spy_b(*a):
-            r = orig_b(*a)
+        def spy_b(*a, **kw):   # all eight outputs plus the internal dL_dconic (debug_out switches the lean mode off)
+            dbg = {}
+            r = orig_b(*a, **dict(kw, debug_out=dbg))
             for k, t in zip(("dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh",
                              "dL_dscales", "dL_drotations"), r):
                 raw[k] = t
-            raw["dL_dconic"] = _C.debug_last["dL_dconic"]
+            raw["dL_dconic"] = dbg["dL_dconic"]
             return r
         _C.rasterize_gaussians_backward = spy_b
-        _C.KEEP_DEBUG = True
         try:
             color.backward(dpix.to(dev))
             torch.cuda.synchronize()
         finally:
             _C.rasterize_gaussians_backward = orig_b
-            _C.KEEP_DEBUG = False
         out["raw_grads"] = {k: v.cpu().numpy() for k, v in raw.items()}
         g = dict(dL_dmeans3D=means.grad, dL_dmeans2D=means2D.grad, dL_dopacity=opac.grad)
         if use_sh:
@@ -123,7 +122,8 @@ def unpack_state(cap, P, W, H):
     depth_bits[perm] = skeys
     o["depth_bits"] = depth_bits                      # per Gaussian; 0xFFFFFFFF = culled
     o["depths"] = depth_bits.view(np.float32)
-    o["slot_base"] = splat[:, 9].view(np.uint32)
+    o["slot_base"] = geom[gl.slot_base:gl.slot_base + 4 * P].view(np.uint32)
+    o["rect"] = geom[gl.rect:gl.rect + 8 * P].view(np.uint32).reshape(P, 2)
     o["final_T"] = img[il.final_T:il.final_T + 4 * N].view(np.float32)
     o["n_contrib"] = img[il.n_contrib:il.n_contrib + 4 * N].view(np.uint32)
     o["ranges"] = img[il.ranges:il.ranges + 8 * T].view(np.uint32).reshape(T, 2)

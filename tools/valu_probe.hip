@@ -1,0 +1,138 @@
+// Probe: what does one gfx950 SIMD sustain per clock for the VALU instruction kinds the blend kernels are
+// made of, at 1 / 2 / 4 / 8 waves per SIMD (one 256*w-thread workgroup per CU -- two of 1024 threads for w = 8 --
+// so that every SIMD holds exactly w waves for the whole run)?  Calibrates bench.py's issue-fraction metric
+// (profiles/r2_valu_probe.txt).  Every wave runs ITERS x 64 independent instructions of one kind (8
+// accumulators, so dependent-issue latency is not what is measured); the clock is measured in the kernel
+// (s_memtime ticks per s_memrealtime tick, 100 MHz).
+//   hipcc --offload-arch=gfx950 -O3 -o tools/valu_probe tools/valu_probe.hip && tools/valu_probe
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+#define ITERS 2048
+
+enum { K_FMA, K_PKFMA, K_EXP, K_RCP, K_MIX, K_CNDMASK, K_DPP, K_CNDMASK_S, K_CMP_CND, K_PKMUL, K_NKINDS };
+static const char* KNAME[] = {"v_fma_f32", "v_pk_fma_f32", "v_exp_f32", "v_rcp_f32", "7 v_fma + 1 v_exp", "v_cndmask_b32 vcc", "v_add_f32 dpp", "v_cndmask_b32 sgpr", "v_cmp + v_cndmask", "v_pk_mul_f32"};
+
+template <int KIND>
+__global__ void __launch_bounds__(1024) probe(float* out, unsigned long long* stamps, unsigned long long* sched)
+{
+	extern __shared__ float pad[];  // sized by the host so that exactly w single-wave workgroups fit per SIMD
+	float a[8];
+	v2f p[8];
+#pragma unroll
+	for (int i = 0; i < 8; i++) { a[i] = 1.0f + threadIdx.x * 1e-3f + i; p[i] = v2f{a[i], a[i] + 0.5f}; }
+	const float b = 0.999f, c = 1e-3f;
+	const v2f b2 = {b, b}, c2 = {c, c};
+	const unsigned long long smask = __builtin_amdgcn_ballot_w64(threadIdx.x & 1);
+	const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+	for (int it = 0; it < ITERS; it++) {
+#pragma unroll
+		for (int u = 0; u < 8; u++) {
+#pragma unroll
+			for (int i = 0; i < 8; i++) {
+				if (KIND == K_FMA) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
+				else if (KIND == K_PKFMA) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p[i]) : "v"(b2), "v"(c2));
+				else if (KIND == K_EXP) asm volatile("v_exp_f32 %0, %0" : "+v"(a[i]));
+				else if (KIND == K_RCP) asm volatile("v_rcp_f32 %0, %0" : "+v"(a[i]));
+				else if (KIND == K_MIX) {
+					if (i == 7) asm volatile("v_exp_f32 %0, %0" : "+v"(a[i]));
+					else asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
+				} else if (KIND == K_CNDMASK) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[i]) : "v"(b) : "vcc");
+				else if (KIND == K_CNDMASK_S) asm volatile("v_cndmask_b32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "s"(smask));
+				else if (KIND == K_CMP_CND) asm volatile("v_cmp_gt_f32 vcc, %0, %1\n\tv_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[i]) : "v"(b) : "vcc");
+				else if (KIND == K_PKMUL) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(p[i]) : "v"(b2));
+				else if (KIND == K_DPP) asm volatile("v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(a[i]));
+			}
+		}
+	}
+	const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+	float s = 0.f;
+#pragma unroll
+	for (int i = 0; i < 8; i++) s += a[i] + p[i].x + p[i].y;
+	out[blockIdx.x * blockDim.x + threadIdx.x] = s + pad[0] * 0.f;
+	if ((threadIdx.x & 63) == 0) {
+		const int wv = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+		stamps[2 * wv] = t1 - t0; stamps[2 * wv + 1] = r1 - r0;
+		// where and when the wave ran: absolute 100 MHz times and the hardware ids
+		sched[4 * wv] = r0; sched[4 * wv + 1] = r1;
+		sched[4 * wv + 2] = __builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_REG_HW_ID
+		sched[4 * wv + 3] = __builtin_amdgcn_s_getreg((31 << 11) | 20);  // HW_REG_XCC_ID
+	}
+}
+
+template <int KIND>
+static void run(int w, float* out, unsigned long long* stamps, unsigned long long* h, unsigned long long* sched)
+{
+	const int per_cu = w == 8 ? 2 : 1, threads = w == 8 ? 1024 : 256 * w;
+	const int nwg = 256 * per_cu, nwaves = nwg * threads / 64;
+	const size_t lds = (160 * 1024) / per_cu / 2 + 1024;  // more than half of a CU's share: exactly per_cu workgroups per CU
+	hipFuncSetAttribute((const void*)probe<KIND>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+	hipEvent_t e0, e1;
+	hipEventCreate(&e0); hipEventCreate(&e1);
+	hipLaunchKernelGGL(probe<KIND>, dim3(nwg), dim3(threads), lds, 0, out, stamps, sched);  // warm-up
+	hipEventRecord(e0, 0);
+	hipLaunchKernelGGL(probe<KIND>, dim3(nwg), dim3(threads), lds, 0, out, stamps, sched);
+	hipEventRecord(e1, 0);
+	hipEventSynchronize(e1);
+	float ms = 0.f;
+	hipEventElapsedTime(&ms, e0, e1);
+	hipMemcpy(h, stamps, (size_t)nwaves * 16, hipMemcpyDeviceToHost);
+	double cyc = 0, real = 0;
+	for (int i = 0; i < nwaves; i++) { cyc += (double)h[2 * i]; real += (double)h[2 * i + 1]; }
+	const double clock_ghz = cyc / real * 0.1;
+	const double instr_per_wave = (double)ITERS * 64.0;
+	// in-kernel: cycles one wave needed per instruction; per SIMD: w waves share it
+	const double cyc_per_instr_wave = (cyc / nwaves) / instr_per_wave;
+	const double cyc_per_instr_simd = cyc_per_instr_wave / w;
+	const double wall_cyc_per_instr_simd = ms * 1e-3 * clock_ghz * 1e9 / (instr_per_wave * w);
+	if (KIND == K_FMA) {  // the schedule the hardware gave this launch
+		unsigned long long* hs = (unsigned long long*)malloc((size_t)nwaves * 32);
+		hipMemcpy(hs, sched, (size_t)nwaves * 32, hipMemcpyDeviceToHost);
+		unsigned long long tmin = ~0ull, tmax = 0, smax = 0;
+		static int per_simd[128 * 64];
+		for (int i = 0; i < 128 * 64; i++) per_simd[i] = 0;
+		for (int i = 0; i < nwaves; i++) {
+			if (hs[4 * i] < tmin) tmin = hs[4 * i];
+			if (hs[4 * i] > smax) smax = hs[4 * i];
+			if (hs[4 * i + 1] > tmax) tmax = hs[4 * i + 1];
+			const unsigned hw = (unsigned)hs[4 * i + 2], xcc = (unsigned)hs[4 * i + 3] & 15u;
+			const unsigned simd = (hw >> 4) & 3u, cu = (hw >> 8) & 15u, sh = (hw >> 12) & 1u, se = (hw >> 13) & 7u;
+			per_simd[((xcc & 7u) * 16 + se * 2 + sh) * 64 + cu * 4 + simd]++;
+		}
+		int hist[64] = {0}, used = 0;
+		for (int i = 0; i < 128 * 64; i++) if (per_simd[i]) { used++; hist[per_simd[i] < 63 ? per_simd[i] : 63]++; }
+		printf("   schedule: %d waves on %d distinct SIMDs; waves per SIMD histogram:", nwaves, used);
+		for (int i = 1; i < 64; i++) if (hist[i]) printf(" %dx%d", hist[i], i);
+		printf("; first start -> last start %.1f us, first start -> last end %.1f us\n", (smax - tmin) * 0.01, (tmax - tmin) * 0.01);
+		free(hs);
+	}
+	printf("%-22s w=%d  kernel %.3f ms  clock %.2f GHz  cycles/instr: per wave %.2f, per SIMD %.2f (in-kernel stamps) %.2f (kernel wall time)\n",
+	       KNAME[KIND], w, ms, clock_ghz, cyc_per_instr_wave, cyc_per_instr_simd, wall_cyc_per_instr_simd);
+}
+
+int main()
+{
+	float* out; unsigned long long* stamps;
+	hipMalloc(&out, 8192 * 64 * 4);
+	hipMalloc(&stamps, 8192 * 16);
+	unsigned long long* sched;
+	hipMalloc(&sched, 8192 * 32);
+	unsigned long long* h = (unsigned long long*)malloc(8192 * 16);
+	const int ws[] = {1, 2, 4, 8};
+	for (int wi = 0; wi < 4; wi++) {
+		const int w = ws[wi];
+		run<K_FMA>(w, out, stamps, h, sched);
+		run<K_PKFMA>(w, out, stamps, h, sched);
+		run<K_EXP>(w, out, stamps, h, sched);
+		run<K_RCP>(w, out, stamps, h, sched);
+		run<K_MIX>(w, out, stamps, h, sched);
+		run<K_CNDMASK>(w, out, stamps, h, sched);
+		run<K_DPP>(w, out, stamps, h, sched);
+		run<K_CNDMASK_S>(w, out, stamps, h, sched);
+		run<K_CMP_CND>(w, out, stamps, h, sched);
+		run<K_PKMUL>(w, out, stamps, h, sched);
+	}
+	return 0;
+}
