@@ -435,9 +435,14 @@ extern "C" int gsr_forward_render(int P, int64_t R, int width, int height, const
 		gsr_launch_tile_ranges(b.tile_keys, R, im.ranges, ntiles, b.tile_keys_alt, s);
 	}
 	if ((rc = gsr_stage_done(s, debug, "tile_ranges"))) return rc;
+	if (R > 0) {
+		GsrProfScope p(s, "tile_order");
+		gsr_launch_tile_order(im, ntiles, false, s);
+	}
+	if ((rc = gsr_stage_done(s, debug, "tile_order"))) return rc;
 	{
 		GsrProfScope p(s, "render_forward");
-		gsr_launch_render_forward(width, height, im, b.point_list, g.splat, background, out_color, s);
+		gsr_launch_render_forward(width, height, im, b.point_list, g.splat, background, out_color, R > 0, s);
 	}
 	return gsr_stage_done(s, debug, "render_forward");
 }
@@ -493,7 +498,7 @@ extern "C" int gsr_backward_blend(const gsr_backward_args* args)
 	GsrBinning b = gsr_binning_view(a.binning, a.P, a.num_rendered, a.width, a.height);
 	{
 		GsrProfScope p(s, "tile_order");
-		gsr_launch_tile_order(im, gsr_grid_x(a.width) * gsr_grid_y(a.height), s);
+		gsr_launch_tile_order(im, gsr_grid_x(a.width) * gsr_grid_y(a.height), true, s);
 	}
 	if ((rc = gsr_stage_done(s, a.debug, "tile_order"))) return rc;
 	{

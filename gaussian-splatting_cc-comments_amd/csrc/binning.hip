@@ -194,11 +194,22 @@ __global__ void __launch_bounds__(256) gsr_tile_ranges_kernel(const uint32_t* __
 
 // ---- dispatch order of the backward blend ---------------------------------------------------------
 // One wave per tile, 4 waves per SIMD: ~2 waves of tiles per launch, so the last tiles to start decide when the
-// kernel ends.  Tiles are handed out in descending order of their work (instances the backward will stage =
-// min(range length, largest n_contrib of the tile)): longest-processing-time-first.  A counting sort on
+// kernel ends.  Tiles are handed out in descending order of their work (backward: instances it will stage =
+// min(range length, largest n_contrib of the tile); forward: range length): longest-processing-time-first.  A counting sort on
 // work / 16 (1024 bins, saturating) by ONE workgroup; the order inside a bin is arbitrary (it only affects
 // scheduling: every tile's result is independent of when it runs).
 #define GSR_ORDER_BINS 1024
+#define GSR_ORDER_PER_THREAD 8
+// work estimate of a tile: instances the backward will stage (tile_max_contrib given) or the length of its range (the
+// forward's upper bound, before anything is known about where its pixels saturate)
+__device__ __forceinline__ uint32_t gsr_tile_work_bin(const uint2* __restrict__ ranges, const uint32_t* __restrict__ tile_max_contrib, uint32_t t)
+{
+	const uint2 r = ranges[t];
+	uint32_t work = r.y - r.x;
+	if (tile_max_contrib) work = min(work, tile_max_contrib[t]);
+	return GSR_ORDER_BINS - 1 - min(work >> 4, (uint32_t)GSR_ORDER_BINS - 1);  // bin 0 = most work
+}
+
 __global__ void __launch_bounds__(1024) gsr_tile_order_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ tile_max_contrib,
                                                               uint32_t ntiles, uint32_t* __restrict__ order)
 {
@@ -206,10 +217,18 @@ __global__ void __launch_bounds__(1024) gsr_tile_order_kernel(const uint2* __res
 	__shared__ uint32_t wsum[1024 / 64];
 	bin[threadIdx.x] = 0;
 	__syncthreads();
-	for (uint32_t t = threadIdx.x; t < ntiles; t += 1024) {
-		const uint2 r = ranges[t];
-		const uint32_t work = min(r.y - r.x, tile_max_contrib[t]);
-		atomicAdd(&bin[GSR_ORDER_BINS - 1 - min(work >> 4, (uint32_t)GSR_ORDER_BINS - 1)], 1u);  // bin 0 = most work
+	// both passes read GSR_ORDER_PER_THREAD tiles per thread with all loads issued before the first use: the kernel is
+	// one workgroup of dependent round trips otherwise (11 us at 8 432 tiles; 4 us this way)
+	for (uint32_t base = 0; base < ntiles; base += 1024 * GSR_ORDER_PER_THREAD) {
+		uint32_t b[GSR_ORDER_PER_THREAD];
+#pragma unroll
+		for (int j = 0; j < GSR_ORDER_PER_THREAD; j++) {
+			const uint32_t t = base + j * 1024 + threadIdx.x;
+			b[j] = t < ntiles ? gsr_tile_work_bin(ranges, tile_max_contrib, t) : 0xffffffffu;
+		}
+#pragma unroll
+		for (int j = 0; j < GSR_ORDER_PER_THREAD; j++)
+			if (b[j] != 0xffffffffu) atomicAdd(&bin[b[j]], 1u);
 	}
 	__syncthreads();
 	const uint32_t c = bin[threadIdx.x];
@@ -217,16 +236,23 @@ __global__ void __launch_bounds__(1024) gsr_tile_order_kernel(const uint2* __res
 	const uint32_t incl = gsr_block_incl_scan<1024>(c, &total, wsum);
 	bin[threadIdx.x] = incl - c;  // first position of the bin
 	__syncthreads();
-	for (uint32_t t = threadIdx.x; t < ntiles; t += 1024) {
-		const uint2 r = ranges[t];
-		const uint32_t work = min(r.y - r.x, tile_max_contrib[t]);
-		order[atomicAdd(&bin[GSR_ORDER_BINS - 1 - min(work >> 4, (uint32_t)GSR_ORDER_BINS - 1)], 1u)] = t;
+	for (uint32_t base = 0; base < ntiles; base += 1024 * GSR_ORDER_PER_THREAD) {
+		uint32_t b[GSR_ORDER_PER_THREAD];
+#pragma unroll
+		for (int j = 0; j < GSR_ORDER_PER_THREAD; j++) {
+			const uint32_t t = base + j * 1024 + threadIdx.x;
+			b[j] = t < ntiles ? gsr_tile_work_bin(ranges, tile_max_contrib, t) : 0xffffffffu;
+		}
+#pragma unroll
+		for (int j = 0; j < GSR_ORDER_PER_THREAD; j++)
+			if (b[j] != 0xffffffffu) order[atomicAdd(&bin[b[j]], 1u)] = base + j * 1024 + threadIdx.x;
 	}
 }
 
-void gsr_launch_tile_order(GsrImage img, int ntiles, hipStream_t s)
+void gsr_launch_tile_order(GsrImage img, int ntiles, bool backward, hipStream_t s)
 {
-	hipLaunchKernelGGL(gsr_tile_order_kernel, dim3(1), dim3(1024), 0, s, img.ranges, img.tile_max_contrib, (uint32_t)ntiles, img.tile_order);
+	hipLaunchKernelGGL(gsr_tile_order_kernel, dim3(1), dim3(1024), 0, s, img.ranges, backward ? img.tile_max_contrib : (const uint32_t*)nullptr,
+	                   (uint32_t)ntiles, img.tile_order);
 }
 
 void gsr_launch_tile_ranges(const uint32_t* tile_keys, int64_t R, uint2* ranges, int ntiles, uint32_t* valid, hipStream_t s)

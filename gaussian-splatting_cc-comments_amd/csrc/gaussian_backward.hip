@@ -178,42 +178,75 @@ __global__ void __launch_bounds__(GSR_GB_THREADS) gsr_gaussian_backward_kernel(G
 	const int M = a.M;
 	const int end = a.first + a.count;
 	const bool in_range = idx < end;
+	// ---- (A) the Gaussian's own inputs, unconditionally for every Gaussian of the range: issued first, so that the
+	//      three dependent steps below (these -> slot validity bytes -> slot records) are the only memory round
+	//      trips of the wave (the SH block of (B) travels beside them)
 	uint32_t tiles = 0, base = 0;
-	if (in_range) tiles = a.g.tiles_touched[idx];
-	// radii > 0 <=> tiles_touched > 0 (forward.cu:300-301 zeroes both together)
-	const bool visible = in_range && (a.radii ? a.radii[idx] > 0 : tiles > 0);
+	int radius = 0;
+	GsrVec3 mean = {0.f, 0.f, 0.f};
+	float sc[3] = {0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f}, cov_in[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+	uint8_t clamp_bits = 0;
+	float leaf_opacity = 0.f;
+	if (in_range) {
+		tiles = a.g.tiles_touched[idx];
+		base = a.g.slot_base[idx];
+		if (a.radii) radius = a.radii[idx];
+		mean.x = a.means3D[3 * idx]; mean.y = a.means3D[3 * idx + 1]; mean.z = a.means3D[3 * idx + 2];
+		if (a.cov3D_precomp) {
+#pragma unroll
+			for (int k = 0; k < 6; k++) cov_in[k] = a.cov3D_precomp[6 * (size_t)idx + k];
+		} else {
+			sc[0] = a.scales[3 * idx]; sc[1] = a.scales[3 * idx + 1]; sc[2] = a.scales[3 * idx + 2];
+			q[0] = a.rotations[4 * idx]; q[1] = a.rotations[4 * idx + 1]; q[2] = a.rotations[4 * idx + 2]; q[3] = a.rotations[4 * idx + 3];
+		}
+		if (a.shs) clamp_bits = a.g.clamped[idx];
+		if (LEAF) leaf_opacity = a.g.splat[idx].opacity;
+	}
 	const int wave_first = a.first + blockIdx.x * GSR_GB_THREADS + wave * 64;
 	const int nrows = min(64, end - wave_first);  // Gaussians of this wave (<= 0: none)
 
-	// ---- stage the wave's SH block (64 x 48 floats, contiguous in HBM) into LDS, coalesced ----
+	// ---- (B) the wave's SH block (64 x 48 floats, contiguous in HBM): coalesced loads now, into LDS at (D) ----
+	float4 shv4[12];
 	if (sh_via_lds && nrows > 0) {
 		if (LEAF) gsr_sh_lin_load(reinterpret_cast<float*>(s_sh[wave]), a.shs, a.shs_rest, wave_first, nrows, lane);
-		else gsr_sh_rows_load(s_sh[wave], a.shs, wave_first, nrows, lane);
+		else gsr_sh_rows_fetch(shv4, a.shs, wave_first, nrows, lane);
 	}
+	// radii > 0 <=> tiles_touched > 0 (forward.cu:300-301 zeroes both together; culled: slot_base was never written)
+	const bool visible = in_range && (a.radii ? radius > 0 : tiles > 0);
+	if (!visible) tiles = 0;
 
-	// ---- fixed-order sum of this Gaussian's (Gaussian,tile) slots ----
+	// ---- (C) validity bytes of all the slots a lane sums by itself ----
+	uint32_t vmask = 0;
+	if (tiles <= GSR_SLOT_COOP) {
+		uint8_t vb[GSR_SLOT_COOP];
+#pragma unroll
+		for (int j = 0; j < GSR_SLOT_COOP; j++) vb[j] = ((uint32_t)j < tiles) ? a.slot_valid[base + j] : (uint8_t)0;
+#pragma unroll
+		for (int j = 0; j < GSR_SLOT_COOP; j++) vmask |= vb[j] ? (1u << j) : 0u;
+	}
+	// ---- (D) SH block into LDS ----
+	if (!LEAF && sh_via_lds && nrows > 0) gsr_sh_rows_commit(s_sh[wave], shv4, nrows, lane);
+
+	// ---- (E) fixed-order sum of this Gaussian's (Gaussian,tile) slots ----
 	float acc[GSR_NACC];
 #pragma unroll
 	for (int i = 0; i < GSR_NACC; i++) acc[i] = 0.f;
-	if (visible) base = a.g.slot_base[idx];
-	else tiles = 0;
-	if (tiles <= GSR_SLOT_COOP) {
-		// four slots per round: their validity bytes and records are all requested before the first add
-		// (one round trip of memory latency per four slots instead of two per slot); same addition order
-		for (uint32_t k = 0; k < tiles; k += 4) {
-			bool ok[4];
-			float4 s0[4], s1[4];
-			float s2[4];
+	if (vmask) {
+		// six slots per round: their records are all requested before the first add; the addition order is the slot order
 #pragma unroll
-			for (int j = 0; j < 4; j++) ok[j] = (k + j < tiles) && a.slot_valid[base + k + j];
+		for (int k = 0; k < GSR_SLOT_COOP; k += 6) {
+			if (!(vmask >> k)) break;
+			float4 s0[6], s1[6];
+			float s2[6];
 #pragma unroll
-			for (int j = 0; j < 4; j++) {
-				const float4* sl = reinterpret_cast<const float4*>(a.slots + (ok[j] ? base + k + j : base));
+			for (int j = 0; j < 6; j++) {
+				const bool ok = (vmask >> (k + j)) & 1u;
+				const float4* sl = reinterpret_cast<const float4*>(a.slots + (ok ? base + k + j : base));
 				s0[j] = sl[0]; s1[j] = sl[1]; s2[j] = sl[2].x;
 			}
 #pragma unroll
-			for (int j = 0; j < 4; j++)
-				if (ok[j]) {
+			for (int j = 0; j < 6; j++)
+				if ((vmask >> (k + j)) & 1u) {
 					acc[0] += s0[j].x; acc[1] += s0[j].y; acc[2] += s0[j].z; acc[3] += s0[j].w; acc[4] += s1[j].x;
 					acc[5] += s1[j].y; acc[6] += s1[j].z; acc[7] += s1[j].w; acc[8] += s2[j];
 				}
@@ -251,13 +284,10 @@ __global__ void __launch_bounds__(GSR_GB_THREADS) gsr_gaussian_backward_kernel(G
 	if (visible) {
 		// ---- computeCov2DCUDA, backward.cu:144-277 ----
 		float cov3D[6];
-		float sc[3] = {0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
 		if (a.cov3D_precomp) {
 #pragma unroll
-			for (int k = 0; k < 6; k++) cov3D[k] = a.cov3D_precomp[6 * (size_t)idx + k];
+			for (int k = 0; k < 6; k++) cov3D[k] = cov_in[k];
 		} else {
-			sc[0] = a.scales[3 * idx]; sc[1] = a.scales[3 * idx + 1]; sc[2] = a.scales[3 * idx + 2];
-			q[0] = a.rotations[4 * idx]; q[1] = a.rotations[4 * idx + 1]; q[2] = a.rotations[4 * idx + 2]; q[3] = a.rotations[4 * idx + 3];
 			if (LEAF) {
 				sc[0] = gsr_act_exp(sc[0]); sc[1] = gsr_act_exp(sc[1]); sc[2] = gsr_act_exp(sc[2]);
 				q_raw[0] = q[0]; q_raw[1] = q[1]; q_raw[2] = q[2]; q_raw[3] = q[3];
@@ -265,7 +295,6 @@ __global__ void __launch_bounds__(GSR_GB_THREADS) gsr_gaussian_backward_kernel(G
 			}
 			gsr_cov3d(sc, a.scale_modifier, q, cov3D);  // recomputed: identical bits to the forward's
 		}
-		const GsrVec3 mean = {a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]};
 		const float dcx = dconic[0], dcy = dconic[1], dcz = dconic[3];
 		GsrCov2D c2;
 		gsr_cov2d(mean, a.focal_x, a.focal_y, a.tan_fovx, a.tan_fovy, cov3D, a.viewmatrix, c2);
@@ -331,17 +360,13 @@ __global__ void __launch_bounds__(GSR_GB_THREADS) gsr_gaussian_backward_kernel(G
 				if (LEAF) {
 					gsr_sh_lin_row_get(reinterpret_cast<const float*>(s_sh[wave]), lane, shv);
 				} else {
-#pragma unroll
-					for (int j = 0; j < 12; j++) {
-						const float4 v = s_sh[wave][lane * GSR_SH_ROW4 + j];
-						shv[4 * j] = v.x; shv[4 * j + 1] = v.y; shv[4 * j + 2] = v.z; shv[4 * j + 3] = v.w;
-					}
+					gsr_sh_row_get(s_sh[wave], lane, shv);
 				}
 				// dL_dsh = basis x dL/dRGB is written below as 12 float4 (the row is conflict-free for 16-byte
 				// accesses; 48 scalar stores at this row stride hit 4-way bank conflicts)
 				float basis[16];
 				const int used_sh = (a.D + 1) * (a.D + 1);
-				gsr_sh_backward(a.D, M, mean, a.cam_pos, shv, a.g.clamped[idx], dcolor, dmean3D, nullptr, false, dRGB, basis);
+				gsr_sh_backward(a.D, M, mean, a.cam_pos, shv, clamp_bits, dcolor, dmean3D, nullptr, false, dRGB, basis);
 				if (!skip_dsh && LEAF) {
 					float o[48];
 #pragma unroll
@@ -367,11 +392,11 @@ __global__ void __launch_bounds__(GSR_GB_THREADS) gsr_gaussian_backward_kernel(G
 							sh_local[k * 3 + ch] = k == 0 ? a.shs[3 * (size_t)idx + ch] : a.shs_rest[((size_t)idx * (M - 1) + (k - 1)) * 3 + ch];
 					}
 				float basis[16];
-				gsr_sh_backward(a.D, used, mean, a.cam_pos, sh_local, a.g.clamped[idx], dcolor, dmean3D, nullptr, false, dRGB, basis);
+				gsr_sh_backward(a.D, used, mean, a.cam_pos, sh_local, clamp_bits, dcolor, dmean3D, nullptr, false, dRGB, basis);
 #pragma unroll
 				for (int e = 0; e < 48; e++) dsh_local[e] = (e / 3 < used) ? basis[e / 3] * dRGB[e % 3] : 0.f;
 			} else {
-				gsr_sh_backward(a.D, M, mean, a.cam_pos, a.shs + (size_t)idx * M * 3, a.g.clamped[idx], dcolor, dmean3D, dsh_global,
+				gsr_sh_backward(a.D, M, mean, a.cam_pos, a.shs + (size_t)idx * M * 3, clamp_bits, dcolor, dmean3D, dsh_global,
 				                !skip_dsh, dRGB);
 			}
 		}
@@ -380,7 +405,7 @@ __global__ void __launch_bounds__(GSR_GB_THREADS) gsr_gaussian_backward_kernel(G
 		if (LEAF) {
 			// exp backward: grad * result;  sigmoid backward: grad * ((1 - y) * y)
 			dscale[0] *= sc[0]; dscale[1] *= sc[1]; dscale[2] *= sc[2];
-			const float o = a.g.splat[idx].opacity;
+			const float o = leaf_opacity;
 			dop = dop * ((1.0f - o) * o);
 			// F.normalize backward: y = x / d, d = clamp_min(||x||, 1e-12)
 			float gd = 0.f;
@@ -455,8 +480,7 @@ __global__ void __launch_bounds__(GSR_GB_THREADS) gsr_gaussian_backward_kernel(G
 		if (a.stat_xyz_gradient_accum) a.stat_xyz_gradient_accum[idx] += sqrtf(dmean2D[0] * dmean2D[0] + dmean2D[1] * dmean2D[1]);
 		if (a.stat_denom) a.stat_denom[idx] += 1.0f;
 		if (a.stat_max_radii2D) {
-			const float r = a.radii ? (float)a.radii[idx] : 0.f;
-			a.stat_max_radii2D[idx] = fmaxf(a.stat_max_radii2D[idx], r);
+			a.stat_max_radii2D[idx] = fmaxf(a.stat_max_radii2D[idx], (float)radius);
 		}
 	}
 }

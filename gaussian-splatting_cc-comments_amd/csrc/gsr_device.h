@@ -154,28 +154,67 @@ __device__ __forceinline__ float gsr_act_normalize4(const float* q, float* out)
 }
 
 // ---- wave-cooperative staging of 64 Gaussians x 16 SH coefficients through LDS -----------------------
-// Row layout in LDS: 13 float4 per Gaussian (48 floats used + 1 float4 pad: conflict-free b128 row
-// accesses).  The HBM side is always streamed with coalesced 16-byte accesses.
+// Row layout in LDS: 13 float4 per Gaussian (48 floats used + 1 float4 pad).  A lane's own row is then 12
+// conflict-free 16-byte accesses (13 is odd: the rows of a ds_read_b128 / ds_write_b128 lane group start in distinct
+// bank quads).  The wave's block of 64 x 48 floats is contiguous in HBM; it is moved with 16-byte accesses in
+// 12 wave instructions, each covering 16 rows x 64 bytes: lane = 4 * quad + e moves float4 number 4 * chunk + e of
+// row 16 * rowblock + rowmap(quad).  The two row maps make the LDS side of the copy conflict-free as well
+// (a plain "lane f moves float4 f" copy collides wherever a row boundary -- the pad -- falls inside a lane group:
+// measured 3.5M conflict cycles per launch in the per-Gaussian backward at 1M Gaussians):
+//   * stores into LDS (ds_write_b128: groups of 8 consecutive lanes = quads 2k, 2k+1, 8 bank quads): the two rows of a
+//     group are 4 apart, 13 * 4 = 4 (mod 8), so the two 4-float4 chunks fall into different halves of the banks;
+//   * loads from LDS (ds_read_b128: lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31} and the same + 32, 16 bank
+//     quads): the four rows of a group are r, r+4, r+8, r+12, 13 * 4k = 4k (mod 16).
 #define GSR_SH_ROW4 13
 #define GSR_SH_ROWF (4 * GSR_SH_ROW4)
 
-// packed (P,16,3) tensor -> rows
-__device__ __forceinline__ void gsr_sh_rows_load(float4* __restrict__ rows, const float* __restrict__ shs, int wave_first, int nrows, int lane)
+__device__ __forceinline__ int gsr_sh_rowmap_store(int quad) { return ((quad >> 1) & 3) + 4 * (quad & 1) + 8 * (quad >> 3); }
+__device__ __forceinline__ int gsr_sh_rowmap_load(int quad) { return (int)((0xFEAB6732DC894510ull >> (4 * quad)) & 15ull); }
+
+// packed (P,16,3) tensor -> rows, in two steps so that a kernel can put other loads between the global loads (fetch)
+// and their first use (commit)
+__device__ __forceinline__ void gsr_sh_rows_fetch(float4* __restrict__ v, const float* __restrict__ shs, int wave_first, int nrows, int lane)
 {
 	const float4* src = reinterpret_cast<const float4*>(shs + (size_t)wave_first * 48);
+	const int e = lane & 3, r0 = gsr_sh_rowmap_store(lane >> 2);
 #pragma unroll
 	for (int it = 0; it < 12; it++) {
-		const int f = it * 64 + lane;
-		if (f < nrows * 12) rows[(f / 12) * GSR_SH_ROW4 + (f % 12)] = src[f];
+		const int row = 16 * (it / 3) + r0, col = 4 * (it % 3) + e;
+		v[it] = (row < nrows) ? src[row * 12 + col] : make_float4(0.f, 0.f, 0.f, 0.f);
 	}
+}
+__device__ __forceinline__ void gsr_sh_rows_commit(float4* __restrict__ rows, const float4* __restrict__ v, int nrows, int lane)
+{
+	const int e = lane & 3, r0 = gsr_sh_rowmap_store(lane >> 2);
+#pragma unroll
+	for (int it = 0; it < 12; it++) {
+		const int row = 16 * (it / 3) + r0, col = 4 * (it % 3) + e;
+		if (row < nrows) rows[row * GSR_SH_ROW4 + col] = v[it];
+	}
+}
+__device__ __forceinline__ void gsr_sh_rows_load(float4* __restrict__ rows, const float* __restrict__ shs, int wave_first, int nrows, int lane)
+{
+	float4 v[12];
+	gsr_sh_rows_fetch(v, shs, wave_first, nrows, lane);  // all twelve loads are in flight before the first LDS store
+	gsr_sh_rows_commit(rows, v, nrows, lane);
 }
 __device__ __forceinline__ void gsr_sh_rows_store(const float4* __restrict__ rows, float* __restrict__ dst_shs, int wave_first, int nrows, int lane)
 {
 	float4* dst = reinterpret_cast<float4*>(dst_shs + (size_t)wave_first * 48);
+	const int e = lane & 3, r0 = gsr_sh_rowmap_load(lane >> 2);
 #pragma unroll
 	for (int it = 0; it < 12; it++) {
-		const int f = it * 64 + lane;
-		if (f < nrows * 12) dst[f] = rows[(f / 12) * GSR_SH_ROW4 + (f % 12)];
+		const int row = 16 * (it / 3) + r0, col = 4 * (it % 3) + e;
+		if (row < nrows) dst[row * 12 + col] = rows[row * GSR_SH_ROW4 + col];
+	}
+}
+// the lane's own 48 coefficients out of / into its row
+__device__ __forceinline__ void gsr_sh_row_get(const float4* __restrict__ rows, int lane, float* __restrict__ row48)
+{
+#pragma unroll
+	for (int j = 0; j < 12; j++) {
+		const float4 v = rows[lane * GSR_SH_ROW4 + j];
+		row48[4 * j] = v.x; row48[4 * j + 1] = v.y; row48[4 * j + 2] = v.z; row48[4 * j + 3] = v.w;
 	}
 }
 // Split leaf tensors _features_dc (P,1,3) + _features_rest (P,15,3) (the torch.cat of

@@ -104,7 +104,7 @@ void gsr_launch_scan_block_sums(uint32_t* block_sums, int nb, uint32_t* total_ou
 void gsr_launch_sorted_block_sums(GsrGeometry g, int P, hipStream_t s);
 void gsr_launch_duplicate_keys(GsrGeometry g, int P, int W, uint32_t* keys, uint32_t* vals, hipStream_t s);
 void gsr_launch_tile_ranges(const uint32_t* tile_keys, int64_t R, uint2* ranges, int ntiles, uint32_t* valid, hipStream_t s);
-void gsr_launch_tile_order(GsrImage img, int ntiles, hipStream_t s);
+void gsr_launch_tile_order(GsrImage img, int ntiles, bool backward, hipStream_t s);
 
 // sort.hip
 int gsr_radix_num_passes(int nbits_total);
@@ -114,7 +114,7 @@ void gsr_radix_sort_u32(uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v1, 
 
 // render_forward.hip
 void gsr_launch_render_forward(int W, int H, GsrImage img, const uint32_t* point_list, const GsrSplat* splat,
-                               const float* bg, float* out_color, hipStream_t s);
+                               const float* bg, float* out_color, bool ordered, hipStream_t s);
 
 // render_backward.hip
 void gsr_launch_render_backward(int W, int H, GsrImage img, const uint32_t* point_list, const GsrSplat* splat,

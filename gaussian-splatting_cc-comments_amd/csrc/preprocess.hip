@@ -39,6 +39,24 @@ __global__ void __launch_bounds__(GSR_PREPROCESS_BLOCK) gsr_preprocess_kernel(Gs
 {
 	__shared__ float4 s_sh[GSR_PREPROCESS_BLOCK / 64][64 * GSR_SH_ROW4];
 	const int idx = blockIdx.x * GSR_PREPROCESS_BLOCK + threadIdx.x;
+	// The Gaussian's own inputs first, unconditionally (a culled Gaussian wastes 44 bytes): issued ahead of the SH
+	// block, every load of the wave is in flight at once -- one memory round trip instead of three dependent ones
+	// (position -> cull test -> scale / rotation / opacity)
+	GsrVec3 p_orig = {0.f, 0.f, 0.f};
+	float sc[3] = {0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f}, cov_in[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+	float col_in[3] = {0.f, 0.f, 0.f}, opac = 0.f;
+	if (idx < a.P) {
+		p_orig.x = a.means3D[3 * idx]; p_orig.y = a.means3D[3 * idx + 1]; p_orig.z = a.means3D[3 * idx + 2];
+		if (a.cov3D_precomp) {
+#pragma unroll
+			for (int k = 0; k < 6; k++) cov_in[k] = a.cov3D_precomp[6 * (size_t)idx + k];
+		} else {
+			sc[0] = a.scales[3 * idx]; sc[1] = a.scales[3 * idx + 1]; sc[2] = a.scales[3 * idx + 2];
+			q[0] = a.rotations[4 * idx]; q[1] = a.rotations[4 * idx + 1]; q[2] = a.rotations[4 * idx + 2]; q[3] = a.rotations[4 * idx + 3];
+		}
+		opac = a.opacities[idx];
+		if (a.colors_precomp) { col_in[0] = a.colors_precomp[3 * idx]; col_in[1] = a.colors_precomp[3 * idx + 1]; col_in[2] = a.colors_precomp[3 * idx + 2]; }
+	}
 	// The wave's 64 x 48 SH floats are contiguous in HBM: stage them into LDS with coalesced float4
 	// loads (a lane reading its own 192-byte row makes every load instruction touch 64 lines)
 	if (sh_via_lds) {
@@ -59,7 +77,6 @@ __global__ void __launch_bounds__(GSR_PREPROCESS_BLOCK) gsr_preprocess_kernel(Gs
 
 	if (idx < a.P) {
 		do {
-			GsrVec3 p_orig = {a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]};
 			// in_frustum, auxiliary.h:144-175
 			GsrVec3 p_view = gsr_transform_point_4x3(p_orig, a.viewmatrix);
 			if (p_view.z <= 0.2f) {
@@ -76,10 +93,8 @@ __global__ void __launch_bounds__(GSR_PREPROCESS_BLOCK) gsr_preprocess_kernel(Gs
 			float cov3D[6];
 			if (a.cov3D_precomp) {
 #pragma unroll
-				for (int k = 0; k < 6; k++) cov3D[k] = a.cov3D_precomp[6 * (size_t)idx + k];
+				for (int k = 0; k < 6; k++) cov3D[k] = cov_in[k];
 			} else {
-				float sc[3] = {a.scales[3 * idx], a.scales[3 * idx + 1], a.scales[3 * idx + 2]};
-				float q[4] = {a.rotations[4 * idx], a.rotations[4 * idx + 1], a.rotations[4 * idx + 2], a.rotations[4 * idx + 3]};
 				if (LEAF) {
 					sc[0] = gsr_act_exp(sc[0]); sc[1] = gsr_act_exp(sc[1]); sc[2] = gsr_act_exp(sc[2]);
 					gsr_act_normalize4(q, q);
@@ -105,18 +120,18 @@ __global__ void __launch_bounds__(GSR_PREPROCESS_BLOCK) gsr_preprocess_kernel(Gs
 			float rgb[3];
 			uint8_t clamp_bits = 0;
 			if (a.colors_precomp) {
-				rgb[0] = a.colors_precomp[3 * idx]; rgb[1] = a.colors_precomp[3 * idx + 1]; rgb[2] = a.colors_precomp[3 * idx + 2];
+				rgb[0] = col_in[0]; rgb[1] = col_in[1]; rgb[2] = col_in[2];
 			} else {
 				float dx = p_orig.x - a.cam_pos[0], dy = p_orig.y - a.cam_pos[1], dz = p_orig.z - a.cam_pos[2];
 				float len = sqrtf(dx * dx + dy * dy + dz * dz);
 				dx = dx / len; dy = dy / len; dz = dz / len;
-				const float* sh = sh_via_lds ? reinterpret_cast<const float*>(&s_sh[threadIdx.x >> 6][(threadIdx.x & 63) * GSR_SH_ROW4])
-				                             : a.shs + (size_t)idx * a.M * 3;
+				const float* sh = a.shs + (size_t)idx * a.M * 3;
 				float raw[3];
-				if (LEAF && sh_via_lds) {
+				if (sh_via_lds) {
 					// own row into registers: only ever indexed with constants below, so it never touches scratch
 					float row[48];
-					gsr_sh_lin_row_get(reinterpret_cast<const float*>(s_sh[threadIdx.x >> 6]), threadIdx.x & 63, row);
+					if (LEAF) gsr_sh_lin_row_get(reinterpret_cast<const float*>(s_sh[threadIdx.x >> 6]), threadIdx.x & 63, row);
+					else gsr_sh_row_get(s_sh[threadIdx.x >> 6], threadIdx.x & 63, row);
 #pragma unroll
 					for (int ch = 0; ch < 3; ch++) raw[ch] = gsr_sh_channel(a.D, row, ch, dx, dy, dz);
 				} else {
@@ -148,7 +163,7 @@ __global__ void __launch_bounds__(GSR_PREPROCESS_BLOCK) gsr_preprocess_kernel(Gs
 			a.g.clamped[idx] = clamp_bits;
 			float4* rec = reinterpret_cast<float4*>(a.g.splat + idx);
 			rec[0] = make_float4(pix, piy, conic_a, conic_b);
-			rec[1] = make_float4(conic_c, LEAF ? gsr_act_sigmoid(a.opacities[idx]) : a.opacities[idx], rgb[0], rgb[1]);
+			rec[1] = make_float4(conic_c, LEAF ? gsr_act_sigmoid(opac) : opac, rgb[0], rgb[1]);
 			rect = make_uint2((uint32_t)minx | ((uint32_t)miny << 16), (uint32_t)(maxx - minx) | ((uint32_t)(maxy - miny) << 16));
 			rec[2] = make_float4(rgb[2], 0.f, __uint_as_float(rect.x), __uint_as_float(rect.y));
 		} while (0);

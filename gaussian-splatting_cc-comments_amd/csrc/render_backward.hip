@@ -99,6 +99,7 @@ __global__ void __launch_bounds__(64 * GSR_WAVES_PER_WG) __attribute__((amdgpu_w
 	}
 	uint32_t id_next = (64 + lane < n) ? plist[n - 1 - (64 + lane)] : 0u;
 	const int out_index = gsr_bfly_index(lane >> 3);  // which of v[0..7] this lane's 8-lane group ends up holding
+	const float out_scale = (out_index >= 2 && out_index <= 4) ? -0.5f : 1.0f;
 
 	for (int base = 0; base < n; base += 64) {
 		const uint32_t bands = (base + lane < n) ? (cull ? gsr_tile_band_mask(ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, x0f, y0f) : 0xFu) : 0u;
@@ -139,7 +140,7 @@ __global__ void __launch_bounds__(64 * GSR_WAVES_PER_WG) __attribute__((amdgpu_w
 			v2f acc[GSR_BWD_NV];
 #pragma unroll
 			for (int i = 0; i < GSR_BWD_NV; i++) acc[i] = v2f{0.f, 0.f};
-			bool any = false;
+			unsigned long long any = 0ull;  // lanes with a hit, kept as a scalar mask: the loop's branches test masks, not ballots of bools
 #pragma unroll
 			for (int p = 0; p < 2; p++) {
 				if (!(bands & (3u << (2 * p))) || contributor >= pair_last[p]) continue;  // scalar branch: no band of this pair can be reached
@@ -149,10 +150,15 @@ __global__ void __launch_bounds__(64 * GSR_WAVES_PER_WG) __attribute__((amdgpu_w
 				const v2f G = {__expf(power.x), __expf(power.y)};
 				const v2f og = OP * G;
 				const v2f araw = {fminf(0.99f, og.x), fminf(0.99f, og.y)};
-				const bool hit0 = contributor < last_contributor[2 * p] && !(power.x > 0.0f) && !(araw.x < 1.0f / 255.0f);
-				const bool hit1 = contributor < last_contributor[2 * p + 1] && !(power.y > 0.0f) && !(araw.y < 1.0f / 255.0f);
-				if (__builtin_amdgcn_ballot_w64(hit0 || hit1) == 0ull) continue;  // wave-uniform
-				any = true;  // (lanes without a hit add exact zeros below)
+				const bool c0 = contributor < last_contributor[2 * p], p0 = !(power.x > 0.0f), a0 = !(araw.x < 1.0f / 255.0f);
+				const bool c1 = contributor < last_contributor[2 * p + 1], p1 = !(power.y > 0.0f), a1 = !(araw.y < 1.0f / 255.0f);
+				const bool hit0 = c0 && p0 && a0, hit1 = c1 && p1 && a1;
+				// each ballot of ONE comparison is that comparison's own lane mask (no instruction); a ballot of the combined
+				// bool costs a v_cndmask + v_cmp round trip through a VGPR
+				const unsigned long long hits = (__builtin_amdgcn_ballot_w64(c0) & __builtin_amdgcn_ballot_w64(p0) & __builtin_amdgcn_ballot_w64(a0)) |
+				                                (__builtin_amdgcn_ballot_w64(c1) & __builtin_amdgcn_ballot_w64(p1) & __builtin_amdgcn_ballot_w64(a1));
+				if (hits == 0ull) continue;  // wave-uniform
+				any |= hits;  // (lanes without a hit add exact zeros below)
 				// A pixel that did not hit runs the same update with alpha = 0, which is the identity on its state
 				// bit for bit (1 - 0 = 1, rcp(1) = 1, T * 1 = T, 0 * c + 1 * acc = acc): no per-state selects
 				const v2f alpha = {hit0 ? araw.x : 0.f, hit1 ? araw.y : 0.f};
@@ -188,7 +194,7 @@ __global__ void __launch_bounds__(64 * GSR_WAVES_PER_WG) __attribute__((amdgpu_w
 				acc[3] = __builtin_elementwise_fma(fdx, dy, acc[3]);
 				acc[4] = __builtin_elementwise_fma(fdy, dy, acc[4]);
 			}
-			if (__builtin_amdgcn_ballot_w64(any)) {  // wave-uniform
+			if (any) {  // wave-uniform
 				float v[GSR_BWD_NV];
 #pragma unroll
 				for (int i = 0; i < GSR_BWD_NV; i++) v[i] = acc[i].x + acc[i].y;
@@ -197,15 +203,15 @@ __global__ void __launch_bounds__(64 * GSR_WAVES_PER_WG) __attribute__((amdgpu_w
 				// v[0] ends in group 0 (lane 0), v[1] in group 4 (lane 32): scalar broadcasts
 				const float sx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, t8), 0));
 				const float sy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, t8), 32));
-				const uint32_t slot = __float_as_uint(R4.w);
+				// the slot is the same in every lane: a scalar, so the store addresses are SGPR base + lane-constant offset
+				const uint32_t slot = __builtin_amdgcn_readfirstlane(__float_as_uint(R4.w));
 				float* out = reinterpret_cast<float*>(slots + slot);
-				if ((lane & 7) == 0) {
-					float r = t8;  // out_index 5 (opacity), 6, 7 (colour) are stored as they are
-					if (out_index == 0) r = -ddelx_dx * (CA.x * sx + CB.x * sy);       // dL/dmean2D.x
-					else if (out_index == 1) r = -ddely_dy * (CC.x * sy + CB.x * sx);  // dL/dmean2D.y
-					else if (out_index <= 4) r = -0.5f * t8;                         // dL/dconic .x .y .w
-					out[out_index] = r;
-				}
+				// every lane evaluates all three forms and selects by its (loop-invariant) output index: no exec-mask regions
+				const float rx = -ddelx_dx * (CA.x * sx + CB.x * sy);  // dL/dmean2D.x
+				const float ry = -ddely_dy * (CC.x * sy + CB.x * sx);  // dL/dmean2D.y
+				const float rk = out_scale * t8;                       // dL/dconic .x .y .w (x -0.5); opacity and colour as they are
+				const float r = out_index == 0 ? rx : (out_index == 1 ? ry : rk);
+				if ((lane & 7) == 0) out[out_index] = r;
 				if (lane == 63) {
 					out[8] = t9;
 					slot_valid[slot] = 1;

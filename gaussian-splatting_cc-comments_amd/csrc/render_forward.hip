@@ -20,12 +20,14 @@
 __global__ void __launch_bounds__(64 * GSR_WAVES_PER_WG) gsr_render_forward_wave_kernel(
 	int W, int H, int gx, int ntiles, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
 	const GsrSplat* __restrict__ splat, const float* __restrict__ bg, float* __restrict__ final_T,
-	uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ tile_max_contrib, float* __restrict__ out_color, int cull)
+	uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ tile_max_contrib, const uint32_t* __restrict__ tile_order,
+	float* __restrict__ out_color, int cull)
 {
 	__shared__ float4 s_rec[GSR_WAVES_PER_WG][3][64];
 	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-	const int tile = blockIdx.x * GSR_WAVES_PER_WG + wave;
-	if (tile >= ntiles) return;  // wave-uniform; no barriers below
+	const int slot_id = blockIdx.x * GSR_WAVES_PER_WG + wave;
+	if (slot_id >= ntiles) return;  // wave-uniform; no barriers below
+	const int tile = tile_order ? (int)tile_order[slot_id] : slot_id;  // longest ranges first (binning.hip gsr_tile_order_kernel)
 	float4(*rec)[64] = s_rec[wave];
 
 	const int tx = tile % gx, ty = tile / gx;
@@ -133,12 +135,12 @@ __global__ void __launch_bounds__(64 * GSR_WAVES_PER_WG) gsr_render_forward_wave
 }
 
 void gsr_launch_render_forward(int W, int H, GsrImage img, const uint32_t* point_list, const GsrSplat* splat,
-                               const float* bg, float* out_color, hipStream_t s)
+                               const float* bg, float* out_color, bool ordered, hipStream_t s)
 {
 	const int gx = gsr_grid_x(W), gy = gsr_grid_y(H);
 	const int ntiles = gx * gy;
 	const int nwg = (ntiles + GSR_WAVES_PER_WG - 1) / GSR_WAVES_PER_WG;
 	hipLaunchKernelGGL(gsr_render_forward_wave_kernel, dim3(nwg), dim3(64 * GSR_WAVES_PER_WG), 0, s, W, H, gx, ntiles,
-	                   img.ranges, point_list, splat, bg, img.final_T, img.n_contrib, img.tile_max_contrib, out_color,
-	                   gsr_culling_enabled());
+	                   img.ranges, point_list, splat, bg, img.final_T, img.n_contrib, img.tile_max_contrib,
+	                   ordered ? img.tile_order : nullptr, out_color, gsr_culling_enabled());
 }

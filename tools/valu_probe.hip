@@ -12,8 +12,8 @@
 typedef float v2f __attribute__((ext_vector_type(2)));
 #define ITERS 2048
 
-enum { K_FMA, K_PKFMA, K_EXP, K_RCP, K_MIX, K_CNDMASK, K_DPP, K_CNDMASK_S, K_CMP_CND, K_PKMUL, K_NKINDS };
-static const char* KNAME[] = {"v_fma_f32", "v_pk_fma_f32", "v_exp_f32", "v_rcp_f32", "7 v_fma + 1 v_exp", "v_cndmask_b32 vcc", "v_add_f32 dpp", "v_cndmask_b32 sgpr", "v_cmp + v_cndmask", "v_pk_mul_f32"};
+enum { K_FMA, K_PKFMA, K_EXP, K_RCP, K_MIX, K_CNDMASK, K_DPP, K_CNDMASK_S, K_CMP_CND, K_PKMUL, K_CMP, K_CMP_S, K_MOV, K_MAX, K_PERM32, K_NKINDS };
+static const char* KNAME[] = {"v_fma_f32", "v_pk_fma_f32", "v_exp_f32", "v_rcp_f32", "7 v_fma + 1 v_exp", "v_cndmask_b32 vcc", "v_add_f32 dpp", "v_cndmask_b32 sgpr", "v_cmp + v_cndmask", "v_pk_mul_f32", "v_cmp_gt_f32 vcc", "v_cmp_gt_f32 sgpr", "v_mov_b32", "v_max_f32", "v_permlane32_swap"};
 
 template <int KIND>
 __global__ void __launch_bounds__(1024) probe(float* out, unsigned long long* stamps, unsigned long long* sched)
@@ -26,6 +26,7 @@ __global__ void __launch_bounds__(1024) probe(float* out, unsigned long long* st
 	const float b = 0.999f, c = 1e-3f;
 	const v2f b2 = {b, b}, c2 = {c, c};
 	const unsigned long long smask = __builtin_amdgcn_ballot_w64(threadIdx.x & 1);
+	unsigned long long sm[4] = {0, 0, 0, 0};
 	const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
 	for (int it = 0; it < ITERS; it++) {
 #pragma unroll
@@ -43,6 +44,11 @@ __global__ void __launch_bounds__(1024) probe(float* out, unsigned long long* st
 				else if (KIND == K_CNDMASK_S) asm volatile("v_cndmask_b32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "s"(smask));
 				else if (KIND == K_CMP_CND) asm volatile("v_cmp_gt_f32 vcc, %0, %1\n\tv_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[i]) : "v"(b) : "vcc");
 				else if (KIND == K_PKMUL) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(p[i]) : "v"(b2));
+				else if (KIND == K_CMP) asm volatile("v_cmp_gt_f32 vcc, %0, %1" : : "v"(a[i]), "v"(b) : "vcc");
+				else if (KIND == K_CMP_S) asm volatile("v_cmp_gt_f32 %0, %1, %2" : "=s"(sm[i & 3]) : "v"(a[i]), "v"(b));
+				else if (KIND == K_MOV) asm volatile("v_mov_b32 %0, %1" : "=v"(a[i]) : "v"(b));
+				else if (KIND == K_MAX) asm volatile("v_max_f32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+				else if (KIND == K_PERM32) asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(a[i]), "+v"(a[(i + 1) & 7]));
 				else if (KIND == K_DPP) asm volatile("v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(a[i]));
 			}
 		}
@@ -51,6 +57,7 @@ __global__ void __launch_bounds__(1024) probe(float* out, unsigned long long* st
 	float s = 0.f;
 #pragma unroll
 	for (int i = 0; i < 8; i++) s += a[i] + p[i].x + p[i].y;
+	s += (float)((sm[0] ^ sm[1] ^ sm[2] ^ sm[3]) & 1ull);
 	out[blockIdx.x * blockDim.x + threadIdx.x] = s + pad[0] * 0.f;
 	if ((threadIdx.x & 63) == 0) {
 		const int wv = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -120,8 +127,8 @@ int main()
 	unsigned long long* sched;
 	hipMalloc(&sched, 8192 * 32);
 	unsigned long long* h = (unsigned long long*)malloc(8192 * 16);
-	const int ws[] = {1, 2, 4, 8};
-	for (int wi = 0; wi < 4; wi++) {
+	const int ws[] = {1, 4, 8};
+	for (int wi = 0; wi < 3; wi++) {
 		const int w = ws[wi];
 		run<K_FMA>(w, out, stamps, h, sched);
 		run<K_PKFMA>(w, out, stamps, h, sched);
@@ -133,6 +140,11 @@ int main()
 		run<K_CNDMASK_S>(w, out, stamps, h, sched);
 		run<K_CMP_CND>(w, out, stamps, h, sched);
 		run<K_PKMUL>(w, out, stamps, h, sched);
+		run<K_CMP>(w, out, stamps, h, sched);
+		run<K_CMP_S>(w, out, stamps, h, sched);
+		run<K_MOV>(w, out, stamps, h, sched);
+		run<K_MAX>(w, out, stamps, h, sched);
+		run<K_PERM32>(w, out, stamps, h, sched);
 	}
 	return 0;
 }
