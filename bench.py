@@ -549,7 +549,7 @@ def run_rank(args, rank, world, dev):
     kern = {}
     allb = dict(fwd_b, **bwd_b)
     for name, v in per_kernel.items():
-        avg = sum(v) / len(v)
+        avg = sum(v) / table_steps   # per step (a stage may be recorded more than once per step: tile_order, depth_sort)
         kern[name] = dict(ms=round(avg, 4), launches=len(v), algorithmic_bytes=allb.get(name),
                           GBps=round(allb[name] / (avg * 1e-3) / 1e9, 1) if allb.get(name) and avg > 0 else None,
                           hbm_frac=round(allb[name] / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 3) if allb.get(name) and avg > 0 else None)

@@ -347,22 +347,37 @@ static int gsr_forward_preprocess_impl(int P, int D, int M, int width, int heigh
 	hipEvent_t ev = event_of[device];
 	if ((rc = gsr_check_hip(hipMemcpyAsync(status_host, a.g.status, GSR_STATUS_WORDS * 4, hipMemcpyDeviceToHost, s), "hipMemcpyAsync(num_rendered)"))) return rc;
 	if ((rc = gsr_check_hip(hipEventRecord(ev, s), "hipEventRecord"))) return rc;
+	// The depth sort orders key - min (keys = float bits of the view-space depth; min / max: partial maxima in the status
+	// words, reduced by every sort workgroup).  Its first three 8-bit passes are always needed and are enqueued at once;
+	// whether bits 24..31 of max - min are populated is known once the status block has landed on the host.
+	const uint32_t* bias = a.g.status + GSR_STATUS_NEGMIN;
 	{
 		GsrProfScope p(s, "depth_sort");
-		int in_first = 1;
-		gsr_radix_sort_u32(a.g.depth_keys, a.g.perm, a.g.depth_keys_alt, a.g.perm_alt, (size_t)P, 32, a.g.sort_table, &in_first, s);
-		// 32 bits = 4 passes: the result is back in (depth_keys, perm)
-		gsr_launch_sorted_block_sums(a.g, P, s);
-		gsr_launch_scan_block_sums(a.g.sorted_block_sums, nb, nullptr, s);
+		gsr_radix_sort_passes(a.g.depth_keys, a.g.perm, a.g.depth_keys_alt, a.g.perm_alt, (size_t)P, 32, 4, 0, 3, a.g.sort_table, bias, s);
 	}
 	if ((rc = gsr_stage_done(s, debug, "depth_sort"))) return rc;
 	if ((rc = gsr_check_hip(hipEventSynchronize(ev), "hipEventSynchronize(num_rendered)"))) return rc;
 	if (status_host[0] & 1u)
 		return gsr_fail(GSR_ERR_PREFILTERED, "Point is filtered although prefiltered is set. This shouldn't happen!");
 	int64_t total = 0;
-	for (int k = 0; k < GSR_COUNT_PARTS; k++) total += (int64_t)status_host[4 + k];
+	uint32_t negmin = 0, kmax = 0;
+	for (int k = 0; k < GSR_COUNT_PARTS; k++) {
+		total += (int64_t)status_host[4 + k];
+		negmin = status_host[GSR_STATUS_NEGMIN + k] > negmin ? status_host[GSR_STATUS_NEGMIN + k] : negmin;
+		kmax = status_host[GSR_STATUS_MAX + k] > kmax ? status_host[GSR_STATUS_MAX + k] : kmax;
+	}
 	*num_rendered_host = total;
-	return GSR_OK;
+	const uint32_t kmin = ~negmin;
+	const uint32_t culled_value = kmax >= kmin ? (kmax - kmin) + 1u : 0u;   // largest biased key (what culled Gaussians sort as)
+	const int fourth = (culled_value >> 24) != 0u || (kmax >= kmin && kmax - kmin == 0xFFFFFFFFu);
+	{
+		GsrProfScope p(s, "depth_sort");
+		if (fourth) gsr_radix_sort_passes(a.g.depth_keys, a.g.perm, a.g.depth_keys_alt, a.g.perm_alt, (size_t)P, 32, 4, 3, 1, a.g.sort_table, bias, s);
+		// three passes leave the order in (depth_keys_alt, perm_alt), four in (depth_keys, perm): recorded in status[2]
+		gsr_launch_sorted_block_sums(a.g, P, fourth ? 0 : 1, s);
+		gsr_launch_scan_block_sums(a.g.sorted_block_sums, nb, nullptr, s);
+	}
+	return gsr_stage_done(s, debug, "depth_sort");
 }
 
 extern "C" int gsr_forward_preprocess(int P, int D, int M, int width, int height, const float* means3D,
@@ -420,13 +435,13 @@ extern "C" int gsr_forward_render(int P, int64_t R, int width, int height, const
 		uint32_t *k1 = even ? b.tile_keys_alt : b.tile_keys, *v1 = even ? b.point_list_alt : b.point_list;
 		{
 			GsrProfScope p(s, "duplicate_keys");
-			gsr_launch_duplicate_keys(g, P, width, k0, v0, s);
+			gsr_launch_duplicate_keys(g, P, width, k0, v0, (uint32_t*)b.sort_table, gsr_radix_clear_words((size_t)R), s);
 		}
 		if ((rc = gsr_stage_done(s, debug, "duplicate_keys"))) return rc;
 		{
 			GsrProfScope p(s, "sort");
 			int in_first = 1;
-			gsr_radix_sort_u32(k0, v0, k1, v1, (size_t)R, bit, b.sort_table, &in_first, s);
+			gsr_radix_sort_u32(k0, v0, k1, v1, (size_t)R, bit, b.sort_table, &in_first, 0, s);  // chunk sums zeroed by duplicate_keys
 		}
 		if ((rc = gsr_stage_done(s, debug, "sort"))) return rc;
 	}

@@ -66,21 +66,23 @@ void gsr_launch_scan_block_sums(uint32_t* block_sums, int nb, uint32_t* total_ou
 // per-workgroup sums of tiles_touched taken in depth order (perm = Gaussian ids sorted by depth)
 __global__ void __launch_bounds__(GSR_PREPROCESS_BLOCK) gsr_sorted_block_sums_kernel(const uint32_t* __restrict__ perm,
                                                                                     const uint32_t* __restrict__ tiles_touched,
-                                                                                    int P, uint32_t* __restrict__ sums)
+                                                                                    int P, uint32_t* __restrict__ sums,
+                                                                                    uint32_t* __restrict__ status, uint32_t result_in_alt)
 {
 	__shared__ uint32_t lds[GSR_PREPROCESS_BLOCK / 64];
 	const int i = blockIdx.x * GSR_PREPROCESS_BLOCK + threadIdx.x;
+	if (i == 0) status[2] = result_in_alt;  // which ping-pong pair holds the depth order: read by the second forward stage and by tests
 	const uint32_t t = (i < P) ? tiles_touched[perm[i]] : 0u;
 	uint32_t total;
 	(void)gsr_block_incl_scan<GSR_PREPROCESS_BLOCK>(t, &total, lds);
 	if (threadIdx.x == 0) sums[blockIdx.x] = total;
 }
 
-void gsr_launch_sorted_block_sums(GsrGeometry g, int P, hipStream_t s)
+void gsr_launch_sorted_block_sums(GsrGeometry g, int P, int result_in_alt, hipStream_t s)
 {
 	const int nb = (P + GSR_PREPROCESS_BLOCK - 1) / GSR_PREPROCESS_BLOCK;
-	hipLaunchKernelGGL(gsr_sorted_block_sums_kernel, dim3(nb), dim3(GSR_PREPROCESS_BLOCK), 0, s, g.perm, g.tiles_touched, P,
-	                   g.sorted_block_sums);
+	hipLaunchKernelGGL(gsr_sorted_block_sums_kernel, dim3(nb), dim3(GSR_PREPROCESS_BLOCK), 0, s, result_in_alt ? g.perm_alt : g.perm,
+	                   g.tiles_touched, P, g.sorted_block_sums, g.status, (uint32_t)result_in_alt);
 }
 
 // ---- key emission ----------------------------------------------------------------------------
@@ -94,8 +96,13 @@ void gsr_launch_sorted_block_sums(GsrGeometry g, int P, hipStream_t s)
 // (rasterizer_impl.cu:107-118).
 __global__ void __launch_bounds__(GSR_PREPROCESS_BLOCK) gsr_duplicate_keys_kernel(GsrGeometry g, int P, uint32_t gx,
                                                                                  uint32_t* __restrict__ keys,
-                                                                                 uint32_t* __restrict__ vals)
+                                                                                 uint32_t* __restrict__ vals,
+                                                                                 uint32_t* __restrict__ clear, size_t clear_words)
 {
+	// zero the chunk sums of the tile sort's passes (sort.hip)
+	for (size_t w = (size_t)blockIdx.x * GSR_PREPROCESS_BLOCK + threadIdx.x; w < clear_words; w += (size_t)gridDim.x * GSR_PREPROCESS_BLOCK)
+		clear[w] = 0u;
+	const uint32_t* __restrict__ perm = g.status[2] ? g.perm_alt : g.perm;  // where the depth sort left its result
 	__shared__ uint32_t lds[GSR_PREPROCESS_BLOCK / 64];
 	__shared__ uint32_t s_start[GSR_PREPROCESS_BLOCK / 64][65];  // start offset of each lane's run, relative to the wave's
 	__shared__ uint32_t s_rect[GSR_PREPROCESS_BLOCK / 64][64];   // minx | miny << 16
@@ -105,7 +112,7 @@ __global__ void __launch_bounds__(GSR_PREPROCESS_BLOCK) gsr_duplicate_keys_kerne
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	uint32_t idx = 0, tiles = 0, rmin = 0, w = 1;
 	if (i < P) {
-		idx = g.perm[i];
+		idx = perm[i];
 		const uint2 rc = g.rect[idx];  // 8-byte gather from a dense array (L2 / Infinity-Cache resident)
 		rmin = rc.x;
 		w = rc.y & 0xffffu;
@@ -143,11 +150,11 @@ __global__ void __launch_bounds__(GSR_PREPROCESS_BLOCK) gsr_duplicate_keys_kerne
 	}
 }
 
-void gsr_launch_duplicate_keys(GsrGeometry g, int P, int W, uint32_t* keys, uint32_t* vals, hipStream_t s)
+void gsr_launch_duplicate_keys(GsrGeometry g, int P, int W, uint32_t* keys, uint32_t* vals, uint32_t* clear, size_t clear_words, hipStream_t s)
 {
 	const int nb = (P + GSR_PREPROCESS_BLOCK - 1) / GSR_PREPROCESS_BLOCK;
 	hipLaunchKernelGGL(gsr_duplicate_keys_kernel, dim3(nb), dim3(GSR_PREPROCESS_BLOCK), 0, s, g, P, (uint32_t)gsr_grid_x(W),
-	                   keys, vals);
+	                   keys, vals, clear, clear_words);
 }
 
 // ---- tile ranges (rasterizer_impl.cu:133-159; ranges zeroed first, :377) -------------------------

@@ -12,7 +12,12 @@
 // spread over this many words so that no address sees more than a few dozen (3 900 adds to ONE word cost
 // 9 us of serialisation); the host adds the parts after the read-back.
 #define GSR_COUNT_PARTS 64
-#define GSR_STATUS_WORDS (4 + GSR_COUNT_PARTS)
+// status words: [0] prefiltered trap, [2] 1 = the depth sort's result is in the ping-pong partners (perm_alt, depth_keys_alt),
+// [4, 68) partial instance counts, [68, 132) partial maxima of ~depth_key, [132, 196) partial maxima of depth_key
+// (visible Gaussians only; the depth sort orders key - min, so only the bits of max - min need passes)
+#define GSR_STATUS_NEGMIN (4 + GSR_COUNT_PARTS)
+#define GSR_STATUS_MAX (4 + 2 * GSR_COUNT_PARTS)
+#define GSR_STATUS_WORDS (4 + 3 * GSR_COUNT_PARTS)
 
 static inline size_t gsr_align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
 static inline int gsr_grid_x(int W) { return (W + GSR_TILE_X - 1) / GSR_TILE_X; }
@@ -29,7 +34,7 @@ struct GsrGeometry {
 	uint2* rect;               // dense copy of the tile rectangle {x | y << 16, w | h << 16}: what the depth-ordered kernels gather
 	uint32_t* slot_base;       // first (Gaussian,tile) gradient slot = offset of the Gaussian's first instance in depth-ordered emission
 	uint8_t* clamped;
-	uint32_t* status;             // [0] prefiltered trap, [4 .. 4+GSR_COUNT_PARTS) partial instance counts
+	uint32_t* status;             // GSR_STATUS_* words
 
 	uint32_t* block_sums;         // (unused since the instance count moved into the status words)
 	uint32_t* sorted_block_sums;  // per-workgroup tile counts in depth order -> exclusive offsets
@@ -101,16 +106,19 @@ void gsr_launch_mark_visible(int P, const float* means3D, const float* viewmatri
 
 // binning.hip
 void gsr_launch_scan_block_sums(uint32_t* block_sums, int nb, uint32_t* total_out, hipStream_t s);
-void gsr_launch_sorted_block_sums(GsrGeometry g, int P, hipStream_t s);
-void gsr_launch_duplicate_keys(GsrGeometry g, int P, int W, uint32_t* keys, uint32_t* vals, hipStream_t s);
+void gsr_launch_sorted_block_sums(GsrGeometry g, int P, int result_in_alt, hipStream_t s);
+void gsr_launch_duplicate_keys(GsrGeometry g, int P, int W, uint32_t* keys, uint32_t* vals, uint32_t* clear, size_t clear_words, hipStream_t s);
 void gsr_launch_tile_ranges(const uint32_t* tile_keys, int64_t R, uint2* ranges, int ntiles, uint32_t* valid, hipStream_t s);
 void gsr_launch_tile_order(GsrImage img, int ntiles, bool backward, hipStream_t s);
 
 // sort.hip
 int gsr_radix_num_passes(int nbits_total);
 size_t gsr_radix_table_bytes(size_t n);
+size_t gsr_radix_clear_words(size_t n);  // leading words of the table that the producer of the keys must zero
+void gsr_radix_sort_passes(uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v1, size_t n, int nbits_total, int npass_total,
+                           int pass_first, int pass_count, void* table_mem, const uint32_t* bias, hipStream_t s);
 void gsr_radix_sort_u32(uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v1, size_t n, int nbits_total, void* table_mem,
-                        int* result_in_first, hipStream_t s);
+                        int* result_in_first, int clear_table, hipStream_t s);
 
 // render_forward.hip
 void gsr_launch_render_forward(int W, int H, GsrImage img, const uint32_t* point_list, const GsrSplat* splat,

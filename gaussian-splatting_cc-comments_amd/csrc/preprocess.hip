@@ -35,7 +35,7 @@ __device__ __forceinline__ float gsr_sh_channel(int deg, const float* sh, int ch
 
 // LEAF: the inputs are the optimiser's raw leaves (gsr_internal.h); activations happen here.
 template <bool LEAF>
-__global__ void __launch_bounds__(GSR_PREPROCESS_BLOCK) gsr_preprocess_kernel(GsrPreprocessArgs a, int sh_via_lds)
+__global__ void __launch_bounds__(GSR_PREPROCESS_BLOCK) gsr_preprocess_kernel(GsrPreprocessArgs a, int sh_via_lds, uint32_t* __restrict__ clear, size_t clear_words)
 {
 	__shared__ float4 s_sh[GSR_PREPROCESS_BLOCK / 64][64 * GSR_SH_ROW4];
 	const int idx = blockIdx.x * GSR_PREPROCESS_BLOCK + threadIdx.x;
@@ -178,30 +178,47 @@ __global__ void __launch_bounds__(GSR_PREPROCESS_BLOCK) gsr_preprocess_kernel(Gs
 	// zeroed by the host side before the launch; the host adds the parts): the count is all the forward needs from this order of the Gaussians -- the
 	// reference's inclusive scan over P (rasterizer_impl.cu:323) would give offsets in ORIGINAL order, and the
 	// offsets that are used here are those of the depth order (gsr_sorted_block_sums_kernel)
-	__shared__ uint32_t wsum[GSR_PREPROCESS_BLOCK / 64];
+	// ... and, the same way, the range of the depth keys of the visible Gaussians: 64-way partial maxima of ~key and key
+	// (sort.hip orders key - min, so the depth sort only needs passes for the bits of max - min)
+	__shared__ uint32_t wsum[GSR_PREPROCESS_BLOCK / 64], wneg[GSR_PREPROCESS_BLOCK / 64], wmax[GSR_PREPROCESS_BLOCK / 64];
 	uint32_t v = tiles;
+	uint32_t kneg = tiles ? ~depth_key : 0u, kmax = tiles ? depth_key : 0u;
 #pragma unroll
-	for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-	if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = v;
+	for (int off = 32; off > 0; off >>= 1) {
+		v += __shfl_down(v, off, 64);
+		kneg = max(kneg, (uint32_t)__shfl_down(kneg, off, 64));
+		kmax = max(kmax, (uint32_t)__shfl_down(kmax, off, 64));
+	}
+	if ((threadIdx.x & 63) == 0) { wsum[threadIdx.x >> 6] = v; wneg[threadIdx.x >> 6] = kneg; wmax[threadIdx.x >> 6] = kmax; }
 	__syncthreads();
 	if (threadIdx.x == 0) {
-		uint32_t t = 0;
+		uint32_t t = 0, n2 = 0, m2 = 0;
 #pragma unroll
-		for (int w = 0; w < GSR_PREPROCESS_BLOCK / 64; w++) t += wsum[w];
-		if (t) atomicAdd(&a.g.status[4 + (blockIdx.x & (GSR_COUNT_PARTS - 1))], t);
+		for (int w = 0; w < GSR_PREPROCESS_BLOCK / 64; w++) { t += wsum[w]; n2 = max(n2, wneg[w]); m2 = max(m2, wmax[w]); }
+		if (t) {
+			const int part = blockIdx.x & (GSR_COUNT_PARTS - 1);
+			atomicAdd(&a.g.status[4 + part], t);
+			atomicMax(&a.g.status[GSR_STATUS_NEGMIN + part], n2);
+			atomicMax(&a.g.status[GSR_STATUS_MAX + part], m2);
+		}
 	}
+	// zero the chunk sums of the depth sort's passes (sort.hip): one word per thread of the first workgroups
+	for (size_t w = (size_t)blockIdx.x * GSR_PREPROCESS_BLOCK + threadIdx.x; w < clear_words; w += (size_t)gridDim.x * GSR_PREPROCESS_BLOCK)
+		clear[w] = 0u;
 }
 
 void gsr_launch_preprocess(const GsrPreprocessArgs& a, hipStream_t s)
 {
 	const int nb = (a.P + GSR_PREPROCESS_BLOCK - 1) / GSR_PREPROCESS_BLOCK;
+	uint32_t* clear = (uint32_t*)a.g.sort_table;
+	const size_t clear_words = gsr_radix_clear_words((size_t)a.P);
 	// LDS-transposed SH path: the flagship layout (16 coefficients), 16-byte aligned tensor
 	int sh_via_lds = (a.shs && !a.colors_precomp && a.M == 16 && ((uintptr_t)a.shs & 15u) == 0) ? 1 : 0;
 	if (a.leaf) {
 		if (((uintptr_t)a.shs_rest & 15u) != 0) sh_via_lds = 0;
-		hipLaunchKernelGGL(gsr_preprocess_kernel<true>, dim3(nb), dim3(GSR_PREPROCESS_BLOCK), 0, s, a, sh_via_lds);
+		hipLaunchKernelGGL(gsr_preprocess_kernel<true>, dim3(nb), dim3(GSR_PREPROCESS_BLOCK), 0, s, a, sh_via_lds, clear, clear_words);
 	} else {
-		hipLaunchKernelGGL(gsr_preprocess_kernel<false>, dim3(nb), dim3(GSR_PREPROCESS_BLOCK), 0, s, a, sh_via_lds);
+		hipLaunchKernelGGL(gsr_preprocess_kernel<false>, dim3(nb), dim3(GSR_PREPROCESS_BLOCK), 0, s, a, sh_via_lds, clear, clear_words);
 	}
 }
 

@@ -9,9 +9,15 @@
 // Within a tile the instances are then in (depth, index) order -- exactly the order of the
 // reference's stable 64-bit sort -- but step 2 needs only ceil(bit / 8) passes over 8-byte pairs.
 //
-// One pass = three launches: per-block digit histogram -> per-digit scan over blocks -> scatter
-// with an in-block stable ranking.  The ranking uses wave64 ballots ("which lanes hold my digit")
-// instead of per-thread counters, so a lane's rank is one popcount.
+// One pass = two launches: per-block digit histogram -> scatter with an in-block stable ranking.  The histogram
+// kernel also adds each block's counts into per-CHUNK sums (a chunk = GSR_SORT_CHUNK consecutive blocks; one atomic
+// per digit per block, 64 adders per address), so the scatter kernel finds its block's offset inside a digit with
+// <= #chunks + GSR_SORT_CHUNK loads per thread and no scan kernel runs in between (it was 6 us x 6 passes per step).
+// The ranking uses wave64 ballots ("which lanes hold my digit") instead of per-thread counters, so a lane's rank is
+// one popcount.
+// Keys may be biased: with a `bias` pointer the sort orders key' = key - min (culled keys 0xFFFFFFFF -> range + 1),
+// min / max taken from 64-way partial maxima left by the preprocess kernel; the depth sort then needs only the
+// passes that cover the bits of max - min (3 instead of 4 for any view whose depth range is below 2^24 float steps).
 #include "gsr_internal.h"
 
 #define GSR_SORT_THREADS 256
@@ -24,6 +30,33 @@
 #define GSR_SORT_ITEMS_LARGE 16
 #define GSR_SORT_ITEMS_SMALL 4
 #define GSR_SORT_SMALL_N (4u << 20)
+#define GSR_SORT_CHUNK 64   // blocks per chunk of the two-level offset table
+
+// min / range of the biased keys from the 64 + 64 partial maxima {max(~key)}, {max(key)} (GsrGeometry::status)
+struct GsrKeyBias { uint32_t min, culled; };  // culled = value that stands for 0xFFFFFFFF keys = (max - min) + 1
+__device__ __forceinline__ GsrKeyBias gsr_sort_bias(const uint32_t* __restrict__ bias, uint32_t* lds2)
+{
+	GsrKeyBias kb = {0u, 0xFFFFFFFFu};
+	if (!bias) return kb;  // uniform
+	if (threadIdx.x < 64) {
+		uint32_t nmin = bias[threadIdx.x], mx = bias[64 + threadIdx.x];
+#pragma unroll
+		for (int off = 32; off > 0; off >>= 1) {
+			nmin = max(nmin, (uint32_t)__shfl_xor(nmin, off, 64));
+			mx = max(mx, (uint32_t)__shfl_xor(mx, off, 64));
+		}
+		if (threadIdx.x == 0) { lds2[0] = ~nmin; lds2[1] = mx; }
+	}
+	__syncthreads();
+	const uint32_t mn = lds2[0], mx = lds2[1];
+	kb.min = mn;
+	kb.culled = (mx >= mn) ? (mx - mn) + 1u : 0u;  // no visible Gaussian at all: every key is the culled value
+	return kb;
+}
+__device__ __forceinline__ uint32_t gsr_sort_key(uint32_t k, const GsrKeyBias& kb, bool biased)
+{
+	return biased ? (k == 0xFFFFFFFFu ? kb.culled : k - kb.min) : k;
+}
 
 // element index of item `it` of this lane: each wave owns a contiguous run of 64 * ITEMS elements,
 // visited 64 at a time, so element order == (wave, it, lane) order and loads are coalesced
@@ -36,10 +69,15 @@ __device__ __forceinline__ size_t gsr_sort_index(int block, int wave, int it, in
 template <int ITEMS>
 __global__ void __launch_bounds__(GSR_SORT_THREADS) gsr_radix_hist_kernel(const uint32_t* __restrict__ keys, size_t n,
                                                                           int shift, uint32_t mask,
-                                                                          uint32_t* __restrict__ table, int nblocks)
+                                                                          uint32_t* __restrict__ table, int nblocks,
+                                                                          uint32_t* __restrict__ chunk_sums, int nchunks,
+                                                                          const uint32_t* __restrict__ bias)
 {
 	__shared__ uint32_t hist[GSR_SORT_RADIX];
+	__shared__ uint32_t s_bias[2];
 	hist[threadIdx.x] = 0;
+	const GsrKeyBias kb = gsr_sort_bias(bias, s_bias);
+	const bool biased = bias != nullptr;
 	__syncthreads();
 	// the histogram does not care which thread counts which element of the block's tile: 16-byte loads
 	constexpr int TILE = GSR_SORT_THREADS * ITEMS;
@@ -51,77 +89,78 @@ __global__ void __launch_bounds__(GSR_SORT_THREADS) gsr_radix_hist_kernel(const 
 		for (int it = 0; it < ITEMS / 4; it++) v[it] = src[it * GSR_SORT_THREADS + threadIdx.x];
 #pragma unroll
 		for (int it = 0; it < ITEMS / 4; it++) {
-			atomicAdd(&hist[(v[it].x >> shift) & mask], 1u);
-			atomicAdd(&hist[(v[it].y >> shift) & mask], 1u);
-			atomicAdd(&hist[(v[it].z >> shift) & mask], 1u);
-			atomicAdd(&hist[(v[it].w >> shift) & mask], 1u);
+			atomicAdd(&hist[(gsr_sort_key(v[it].x, kb, biased) >> shift) & mask], 1u);
+			atomicAdd(&hist[(gsr_sort_key(v[it].y, kb, biased) >> shift) & mask], 1u);
+			atomicAdd(&hist[(gsr_sort_key(v[it].z, kb, biased) >> shift) & mask], 1u);
+			atomicAdd(&hist[(gsr_sort_key(v[it].w, kb, biased) >> shift) & mask], 1u);
 		}
 	} else {
 		const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll
 		for (int it = 0; it < ITEMS; it++) {
 			const size_t i = gsr_sort_index<ITEMS>(blockIdx.x, wave, it, lane);
-			if (i < n) atomicAdd(&hist[(keys[i] >> shift) & mask], 1u);
+			if (i < n) atomicAdd(&hist[(gsr_sort_key(keys[i], kb, biased) >> shift) & mask], 1u);
 		}
 	}
 	__syncthreads();
-	table[(size_t)threadIdx.x * nblocks + blockIdx.x] = hist[threadIdx.x];  // [digit][block]
-}
-
-// one workgroup per digit: exclusive scan of that digit's counts over the blocks, digit total out
-__global__ void __launch_bounds__(GSR_SORT_THREADS) gsr_radix_rowscan_kernel(uint32_t* __restrict__ table, int nblocks,
-                                                                             uint32_t* __restrict__ digit_total)
-{
-	__shared__ uint32_t wsum[GSR_SORT_THREADS / 64];
-	uint32_t* row = table + (size_t)blockIdx.x * nblocks;
-	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-	uint32_t carry = 0;
-	for (int base = 0; base < nblocks; base += GSR_SORT_THREADS) {
-		const int i = base + threadIdx.x;
-		const uint32_t v = (i < nblocks) ? row[i] : 0u;
-		uint32_t incl = v;
-#pragma unroll
-		for (int off = 1; off < 64; off <<= 1) {
-			const uint32_t t = __shfl_up(incl, off, 64);
-			if (lane >= off) incl += t;
-		}
-		if (lane == 63) wsum[wave] = incl;
-		__syncthreads();
-		uint32_t wbase = 0, tot = 0;
-#pragma unroll
-		for (int w = 0; w < GSR_SORT_THREADS / 64; w++) {
-			const uint32_t s = wsum[w];
-			if (w < wave) wbase += s;
-			tot += s;
-		}
-		__syncthreads();
-		if (i < nblocks) row[i] = carry + wbase + incl - v;
-		carry += tot;
-	}
-	if (threadIdx.x == 0) digit_total[blockIdx.x] = carry;
+	const uint32_t c = hist[threadIdx.x];
+	table[(size_t)blockIdx.x * GSR_SORT_RADIX + threadIdx.x] = c;  // [block][digit]: a block's row is one coalesced kilobyte
+	if (c) atomicAdd(&chunk_sums[(size_t)(blockIdx.x / GSR_SORT_CHUNK) * GSR_SORT_RADIX + threadIdx.x], c);  // [chunk][digit], zeroed beforehand
 }
 
 template <int ITEMS>
 __global__ void __launch_bounds__(GSR_SORT_THREADS) gsr_radix_scatter_kernel(
 	const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, uint32_t* __restrict__ keys_out,
 	uint32_t* __restrict__ vals_out, size_t n, int shift, int nbits, const uint32_t* __restrict__ table, int nblocks,
-	const uint32_t* __restrict__ digit_total)
+	const uint32_t* __restrict__ chunk_sums, int nchunks, const uint32_t* __restrict__ bias)
 {
 	__shared__ uint32_t wcount[GSR_SORT_THREADS / 64][GSR_SORT_RADIX];  // per-wave digit counts, then local bases
 	__shared__ uint32_t gofs[GSR_SORT_RADIX];                           // global base of a digit minus its local base
 	__shared__ uint32_t wsum[GSR_SORT_THREADS / 64];
 	constexpr int TILE = GSR_SORT_THREADS * ITEMS;
 	__shared__ uint32_t skey[TILE], sval[TILE];       // the block's elements in digit order
+	__shared__ uint32_t s_bias[2];
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	const uint32_t mask = (1u << nbits) - 1u;
+	const bool biased = bias != nullptr;
 
 #pragma unroll
 	for (int w = 0; w < GSR_SORT_THREADS / 64; w++) wcount[w][threadIdx.x] = 0;
 
-	// global exclusive base of digit d = (sum of totals of smaller digits) + this block's offset in d
+	// the block's elements first: these loads need nothing from the table walk below and travel beside it
+	uint32_t key[ITEMS], val[ITEMS], rank[ITEMS];
+#pragma unroll
+	for (int it = 0; it < ITEMS; it++) {
+		const size_t i = gsr_sort_index<ITEMS>(blockIdx.x, wave, it, lane);
+		const bool valid = i < n;
+		key[it] = valid ? keys_in[i] : 0u;
+		val[it] = valid ? vals_in[i] : 0u;
+	}
+
+	// global exclusive base of digit d = (sum of totals of smaller digits) + this block's offset in d.  Thread d walks the
+	// chunk sums of its digit (total, and the part in front of this block's chunk) and the counts of the blocks of this
+	// chunk in front of this block: all loads of a group are issued before the first add.
 	uint32_t my_gbase;
 	{
-		const uint32_t v = digit_total[threadIdx.x];
+		uint32_t v = 0, before = 0;
+		const int my_chunk = blockIdx.x / GSR_SORT_CHUNK;
+		// [chunk][digit] and [block][digit] rows: thread d reads word d of every row, so each load instruction of the
+		// workgroup fetches one contiguous kilobyte; 16 loads are in flight per group
+		for (int c0 = 0; c0 < nchunks; c0 += 16) {
+			uint32_t t[16];
+#pragma unroll
+			for (int j = 0; j < 16; j++) t[j] = (c0 + j < nchunks) ? chunk_sums[(size_t)(c0 + j) * GSR_SORT_RADIX + threadIdx.x] : 0u;
+#pragma unroll
+			for (int j = 0; j < 16; j++) { v += t[j]; before += (c0 + j < my_chunk) ? t[j] : 0u; }
+		}
+		const int b0 = my_chunk * GSR_SORT_CHUNK, nb = (int)blockIdx.x - b0;  // blocks of this chunk in front of this one
+		for (int j0 = 0; j0 < nb; j0 += 16) {
+			uint32_t t[16];
+#pragma unroll
+			for (int j = 0; j < 16; j++) t[j] = (j0 + j < nb) ? table[(size_t)(b0 + j0 + j) * GSR_SORT_RADIX + threadIdx.x] : 0u;
+#pragma unroll
+			for (int j = 0; j < 16; j++) before += t[j];
+		}
 		uint32_t incl = v;
 #pragma unroll
 		for (int off = 1; off < 64; off <<= 1) {
@@ -134,19 +173,17 @@ __global__ void __launch_bounds__(GSR_SORT_THREADS) gsr_radix_scatter_kernel(
 #pragma unroll
 		for (int w = 0; w < GSR_SORT_THREADS / 64; w++)
 			if (w < wave) wb += wsum[w];
-		my_gbase = wb + incl - v + table[(size_t)threadIdx.x * nblocks + blockIdx.x];
+		my_gbase = wb + incl - v + before;
 	}
+	const GsrKeyBias kb = gsr_sort_bias(bias, s_bias);  // (contains the barrier that also publishes wsum's readers' results)
 	__syncthreads();
 
-	uint32_t key[ITEMS], val[ITEMS], rank[ITEMS];
 	uint32_t* mycount = wcount[wave];
 #pragma unroll
 	for (int it = 0; it < ITEMS; it++) {
 		const size_t i = gsr_sort_index<ITEMS>(blockIdx.x, wave, it, lane);
 		const bool valid = i < n;
-		key[it] = valid ? keys_in[i] : 0u;
-		val[it] = valid ? vals_in[i] : 0u;
-		const uint32_t d = (key[it] >> shift) & mask;
+		const uint32_t d = (gsr_sort_key(key[it], kb, biased) >> shift) & mask;
 		unsigned long long peers = __builtin_amdgcn_ballot_w64(valid);
 		for (int b = 0; b < nbits; b++) {
 			const bool bit = (d >> b) & 1u;
@@ -195,7 +232,7 @@ __global__ void __launch_bounds__(GSR_SORT_THREADS) gsr_radix_scatter_kernel(
 	for (int it = 0; it < ITEMS; it++) {
 		const size_t i = gsr_sort_index<ITEMS>(blockIdx.x, wave, it, lane);
 		if (i < n) {
-			const uint32_t lp = mycount[(key[it] >> shift) & mask] + rank[it];
+			const uint32_t lp = mycount[(gsr_sort_key(key[it], kb, biased) >> shift) & mask] + rank[it];
 			skey[lp] = key[it];
 			sval[lp] = val[it];
 		}
@@ -205,55 +242,75 @@ __global__ void __launch_bounds__(GSR_SORT_THREADS) gsr_radix_scatter_kernel(
 	const uint32_t count = (uint32_t)((n - first < (size_t)TILE) ? (n - first) : (size_t)TILE);
 	for (uint32_t i = threadIdx.x; i < count; i += GSR_SORT_THREADS) {
 		const uint32_t k = skey[i];
-		const uint32_t dst = gofs[(k >> shift) & mask] + i;
-		keys_out[dst] = k;
-		vals_out[dst] = sval[i];
+		const uint32_t dst = gofs[(gsr_sort_key(k, kb, biased) >> shift) & mask] + i;
+		if (dst < n) {  // always true for consistent tables; a corrupted table must not turn into a wild store
+			keys_out[dst] = k;
+			vals_out[dst] = sval[i];
+		}
 	}
 }
 
 int gsr_radix_num_passes(int nbits_total) { return (nbits_total + 7) / 8; }
 
 static inline int gsr_sort_items(size_t n) { return n <= GSR_SORT_SMALL_N ? GSR_SORT_ITEMS_SMALL : GSR_SORT_ITEMS_LARGE; }
+static inline size_t gsr_sort_nblocks(size_t n) { const size_t tile = (size_t)GSR_SORT_THREADS * gsr_sort_items(n); return (n + tile - 1) / tile; }
+static inline size_t gsr_sort_nchunks(size_t n) { return (gsr_sort_nblocks(n) + GSR_SORT_CHUNK - 1) / GSR_SORT_CHUNK; }
+#define GSR_SORT_MAX_PASSES 4
+
+// table memory: [chunk sums of up to 4 passes: 4 x nchunks x RADIX u32, zero before the first pass] [nblocks x RADIX u32]
+size_t gsr_radix_clear_words(size_t n) { return (size_t)GSR_SORT_MAX_PASSES * GSR_SORT_RADIX * gsr_sort_nchunks(n); }
 
 size_t gsr_radix_table_bytes(size_t n)
 {
-	const size_t tile = (size_t)GSR_SORT_THREADS * gsr_sort_items(n);
-	const size_t nblocks = (n + tile - 1) / tile;
-	return gsr_align_up((nblocks * GSR_SORT_RADIX + GSR_SORT_RADIX) * sizeof(uint32_t));
+	return gsr_align_up((gsr_radix_clear_words(n) + gsr_sort_nblocks(n) * GSR_SORT_RADIX) * sizeof(uint32_t));
 }
 
 template <int ITEMS>
 static void gsr_radix_pass(const uint32_t* ki, const uint32_t* vi, uint32_t* ko, uint32_t* vo, size_t n, int shift, int bits,
-                           uint32_t* table, uint32_t* digit_total, hipStream_t s)
+                           uint32_t* table, uint32_t* chunk_sums, int nchunks, const uint32_t* bias, hipStream_t s)
 {
 	const int nblocks = (int)((n + (size_t)GSR_SORT_THREADS * ITEMS - 1) / ((size_t)GSR_SORT_THREADS * ITEMS));
 	const uint32_t mask = (1u << bits) - 1u;
-	hipLaunchKernelGGL(gsr_radix_hist_kernel<ITEMS>, dim3(nblocks), dim3(GSR_SORT_THREADS), 0, s, ki, n, shift, mask, table, nblocks);
-	hipLaunchKernelGGL(gsr_radix_rowscan_kernel, dim3(GSR_SORT_RADIX), dim3(GSR_SORT_THREADS), 0, s, table, nblocks, digit_total);
+	hipLaunchKernelGGL(gsr_radix_hist_kernel<ITEMS>, dim3(nblocks), dim3(GSR_SORT_THREADS), 0, s, ki, n, shift, mask, table, nblocks,
+	                   chunk_sums, nchunks, bias);
 	hipLaunchKernelGGL(gsr_radix_scatter_kernel<ITEMS>, dim3(nblocks), dim3(GSR_SORT_THREADS), 0, s, ki, vi, ko, vo, n, shift, bits,
-	                   table, nblocks, digit_total);
+	                   table, nblocks, chunk_sums, nchunks, bias);
+}
+
+// Runs passes [pass_first, pass_first + pass_count) of the LSD sort on key bits [0, nbits_total) (spread evenly over
+// npass_total passes).  Pass p reads (k0,v0) when p is even and (k1,v1) when odd and writes the other pair; the chunk sums
+// in table_mem must be zero (each pass uses its own slice).  bias: NULL, or the 128 partial maxima of gsr_sort_bias().
+void gsr_radix_sort_passes(uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v1, size_t n, int nbits_total, int npass_total,
+                           int pass_first, int pass_count, void* table_mem, const uint32_t* bias, hipStream_t s)
+{
+	if (n == 0) return;
+	const int items = gsr_sort_items(n);
+	const int nchunks = (int)gsr_sort_nchunks(n);
+	uint32_t* chunk_base = (uint32_t*)table_mem;
+	uint32_t* table = chunk_base + gsr_radix_clear_words(n);
+	int shift = 0;
+	for (int p = 0; p < npass_total && p < pass_first + pass_count; p++) {
+		const int bits = (nbits_total - shift + (npass_total - p) - 1) / (npass_total - p);  // spread bits evenly over passes
+		if (p >= pass_first) {
+			uint32_t *ki = (p % 2 == 0) ? k0 : k1, *vi = (p % 2 == 0) ? v0 : v1;
+			uint32_t *ko = (p % 2 == 0) ? k1 : k0, *vo = (p % 2 == 0) ? v1 : v0;
+			uint32_t* cs = chunk_base + (size_t)p * GSR_SORT_RADIX * nchunks;
+			if (items == GSR_SORT_ITEMS_SMALL) gsr_radix_pass<GSR_SORT_ITEMS_SMALL>(ki, vi, ko, vo, n, shift, bits, table, cs, nchunks, bias, s);
+			else gsr_radix_pass<GSR_SORT_ITEMS_LARGE>(ki, vi, ko, vo, n, shift, bits, table, cs, nchunks, bias, s);
+		}
+		shift += bits;
+	}
 }
 
 // Sorts on key bits [0, nbits_total).  Ping-pongs between (k0,v0) and (k1,v1); the sorted result
 // ends in (k0,v0) when the pass count is even and in (k1,v1) when odd -- returned through *in_first.
+// clear_table: zero the chunk sums here (a memset on the stream); 0 when the kernel that produced the keys already did.
 void gsr_radix_sort_u32(uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v1, size_t n, int nbits_total, void* table_mem,
-                        int* result_in_first, hipStream_t s)
+                        int* result_in_first, int clear_table, hipStream_t s)
 {
 	const int npass = gsr_radix_num_passes(nbits_total);
 	*result_in_first = (npass % 2 == 0) ? 1 : 0;
 	if (n == 0 || npass == 0) { *result_in_first = 1; return; }
-	const int items = gsr_sort_items(n);
-	const size_t tile = (size_t)GSR_SORT_THREADS * items;
-	const size_t nblocks = (n + tile - 1) / tile;
-	uint32_t* table = (uint32_t*)table_mem;
-	uint32_t* digit_total = table + nblocks * GSR_SORT_RADIX;
-	int shift = 0;
-	for (int p = 0; p < npass; p++) {
-		const int bits = (nbits_total - shift + (npass - p) - 1) / (npass - p);  // spread bits evenly over passes
-		uint32_t *ki = (p % 2 == 0) ? k0 : k1, *vi = (p % 2 == 0) ? v0 : v1;
-		uint32_t *ko = (p % 2 == 0) ? k1 : k0, *vo = (p % 2 == 0) ? v1 : v0;
-		if (items == GSR_SORT_ITEMS_SMALL) gsr_radix_pass<GSR_SORT_ITEMS_SMALL>(ki, vi, ko, vo, n, shift, bits, table, digit_total, s);
-		else gsr_radix_pass<GSR_SORT_ITEMS_LARGE>(ki, vi, ko, vo, n, shift, bits, table, digit_total, s);
-		shift += bits;
-	}
+	if (clear_table) (void)hipMemsetAsync(table_mem, 0, gsr_radix_clear_words(n) * sizeof(uint32_t), s);
+	gsr_radix_sort_passes(k0, v0, k1, v1, n, nbits_total, npass, 0, npass, table_mem, nullptr, s);
 }

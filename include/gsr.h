@@ -56,15 +56,16 @@ size_t gsr_backward_scratch_bytes(int P, int64_t num_rendered);
 /* Byte offsets of the typed arrays inside each blob (introspection for tests / debuggers). */
 typedef struct {
 	size_t splat;          /* [P] 48-byte records: xy(2f) conic+opacity(4f) rgb(3f) slot_base(u32) rect_min(u16x2) rect_wh(u16x2) */
-	size_t depth_keys;     /* [P] u32: after the call, depth bits sorted ascending (culled = 0xFFFFFFFF last) */
-	size_t depth_keys_alt; /* [P] u32 sort ping-pong */
-	size_t perm;           /* [P] u32 Gaussian ids in (depth, id) order */
+	size_t depth_keys;     /* [P] u32: after the call, depth bits sorted ascending (culled = 0xFFFFFFFF last) -- in this array or in */
+	size_t depth_keys_alt; /* [P] u32 its ping-pong partner: status word 2 says which (1 = the _alt pair; three radix passes sufficed) */
+	size_t perm;           /* [P] u32 Gaussian ids in (depth, id) order (or in perm_alt, see above) */
 	size_t perm_alt;       /* [P] u32 sort ping-pong */
 	size_t tiles_touched;  /* [P] u32 */
 	size_t rect;           /* [P] uint2: tile rectangle {min x | min y << 16, width | height << 16} (dense copy of the record's) */
 	size_t slot_base;      /* [P] u32: first gradient slot of the Gaussian = offset of its first instance in depth-ordered emission */
 	size_t clamped;        /* [P] u8 bit c set = colour channel c was clamped at 0 */
-	size_t status;         /* u32 device status words (0: prefiltered trap; 4..67: partial instance counts) */
+	size_t status;         /* u32 device status words (0: prefiltered trap; 2: depth order in the _alt pair; 4..67: partial instance
+	                          counts; 68..131 / 132..195: partial maxima of ~depth key / depth key of the visible Gaussians) */
 	size_t scan_temp;      /* per-workgroup tile counts: original order, then depth order */
 	size_t sort_table;     /* radix histogram table of the depth sort */
 	size_t total;

@@ -118,8 +118,9 @@ def _properties(name, check_linearity=True):
     assert bool((tile_keys[1:] >= tile_keys[:-1]).all()), "instances sorted by tile"
     assert int(tile_keys.max()) < T
     # depth bits per Gaussian from the depth sort's outputs
-    perm = u32(cap["geom"], gl.perm, P).to(torch.int64)
-    skeys = u32(cap["geom"], gl.depth_keys, P).to(torch.int64) & 0xFFFFFFFF
+    in_alt = int(u32(cap["geom"], gl.status, 4)[2])   # the depth sort's result: in the ping-pong partners after three passes
+    perm = u32(cap["geom"], gl.perm_alt if in_alt else gl.perm, P).to(torch.int64)
+    skeys = u32(cap["geom"], gl.depth_keys_alt if in_alt else gl.depth_keys, P).to(torch.int64) & 0xFFFFFFFF
     assert bool((skeys[1:] >= skeys[:-1]).all()), "Gaussians sorted by depth"
     assert torch.equal(torch.sort(perm).values, torch.arange(P, device=dev)), "perm is a permutation"
     depth_of = torch.empty(P, dtype=torch.int64, device=dev)

@@ -282,6 +282,33 @@ def test_hip_sh_colour_and_gradient_match_reference_fixture_directly():
         assert np.all(got_dsh[:, used:, :] == 0)
 
 
+def test_depth_sort_pass_count_follows_depth_range():
+    """The depth sort orders (depth bits - smallest depth bits) and runs only the radix passes those bits need: three
+    when the view's depth range spans fewer than 2^24 float steps (result in the ping-pong partner arrays), four
+    otherwise.  Both variants must give the oracle's order exactly (ties, culled Gaussians last)."""
+    _need_gpu()
+    # (a) compact depth range: camera at distance 4 from a cube of side 3 -> depths 2.5 .. 5.5
+    scene = gsr_scene.make_scene(6000, -3.0, sh_degree=1, seed=13)
+    cam = gsr_scene.make_camera(160, 96)
+    o = util.oracle_forward(scene, cam, 1)
+    h = util.hip_forward_backward(scene, cam, 1, None)
+    check_forward(h, o, cam)
+    assert h["depth_sort_result_in_alt"] == 1
+    # (b) depths from 0.2 to ~200: the float bits span more than 2^24 steps
+    g = torch.Generator().manual_seed(3)
+    means = scene.means3D.clone()
+    means[:, 2] = torch.exp(torch.rand(6000, generator=g) * 7.0 - 1.7) - 4.0   # view-space z = means.z + 4 in (0.18, 200)
+    means[:, :2] *= (means[:, 2:3] + 4.0) * 0.3
+    means[::50] = means[7]                                                        # clones: equal depth keys
+    far = scene._replace(means3D=means.contiguous(), scales=(scene.scales * (means[:, 2:3] + 4.0).clamp(min=0.3)).contiguous())
+    o = util.oracle_forward(far, cam, 1)
+    z = o["depths"][o["radii"] > 0]
+    assert z.min() < 0.5 and z.max() > 100.0
+    h = util.hip_forward_backward(far, cam, 1, None)
+    check_forward(h, o, cam)
+    assert h["depth_sort_result_in_alt"] == 0
+
+
 def test_smoke_entry():
     _need_gpu()
     import __graft_entry__

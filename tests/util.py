@@ -115,8 +115,12 @@ def unpack_state(cap, P, W, H):
     o["tiles_touched"] = geom[gl.tiles_touched:gl.tiles_touched + 4 * P].view(np.uint32)
     o["clamped_bits"] = geom[gl.clamped:gl.clamped + P]
     # depth sort outputs: Gaussian ids in (depth, id) order and their sorted depth bits
-    perm = geom[gl.perm:gl.perm + 4 * P].view(np.uint32)
-    skeys = geom[gl.depth_keys:gl.depth_keys + 4 * P].view(np.uint32)
+    # status word 2: the depth sort ended in the ping-pong partners (three passes sufficed for the depth range)
+    in_alt = int(geom[gl.status:gl.status + 16].view(np.uint32)[2])
+    o["depth_sort_result_in_alt"] = in_alt
+    p_off, k_off = (gl.perm_alt, gl.depth_keys_alt) if in_alt else (gl.perm, gl.depth_keys)
+    perm = geom[p_off:p_off + 4 * P].view(np.uint32)
+    skeys = geom[k_off:k_off + 4 * P].view(np.uint32)
     o["perm"], o["sorted_depth_keys"] = perm, skeys
     depth_bits = np.empty(P, np.uint32)
     depth_bits[perm] = skeys
