@@ -62,13 +62,16 @@ def render(means3D, scales, rotations, opacities, shs, viewmatrix, projmatrix, c
     Rm = torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y),
                       2 * (x * y + r * z), 1 - 2 * (x * x + z * z), 2 * (y * z - r * x),
                       2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y)], 1).reshape(-1, 3, 3)
-    Mm = Rm * (scale_modifier * scales[idx])[:, None, :]
+    sv = scales[idx]
+    Mm = Rm * (sv + (scale_modifier - 1.0) * sv.detach())[:, None, :]   # dL/dscale without the modifier (backward.cu:281-345)
     Sigma = Mm @ Mm.transpose(1, 2)
-    # computeCov2D (forward.cu:84-140): the clamped t.xy carry no gradient through the clamp
+    # computeCov2D (forward.cu:84-140): where the clamp is active the clamped value is a constant for the gradient
+    # (backward.cu:174-178, 265-266; SURVEY.md Appendix A 14 ii)
     tz = t[:, 2]
     limx, limy = 1.3 * tanfovx, 1.3 * tanfovy
-    tx = torch.minimum(torch.maximum(t[:, 0] / tz, torch.tensor(-limx, dtype=dt)), torch.tensor(limx, dtype=dt)) * tz
-    ty = torch.minimum(torch.maximum(t[:, 1] / tz, torch.tensor(-limy, dtype=dt)), torch.tensor(limy, dtype=dt)) * tz
+    in_x, in_y = (t[:, 0] / tz).detach().abs() <= limx, (t[:, 1] / tz).detach().abs() <= limy
+    tx = torch.where(in_x, t[:, 0], (torch.sign(t[:, 0]) * limx * tz).detach())
+    ty = torch.where(in_y, t[:, 1], (torch.sign(t[:, 1]) * limy * tz).detach())
     Vn = idx.shape[0]
     J = torch.zeros(Vn, 2, 3, dtype=dt)
     J[:, 0, 0] = fx / tz

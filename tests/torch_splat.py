@@ -7,8 +7,10 @@ and the HIP kernels share, so agreement with the oracle's analytic backward chec
 Dense (pixels x Gaussians), for small scenes only.  Discrete decisions (tile membership, depth
 order) are taken from the oracle state; the accept/reject masks are recomputed here from detached
 values.  The reference's deliberate deviations from the true gradient are encoded as in
-SURVEY.md Appendix A item 14: straight-through 0.99 clamp; masks carry no gradient.
-Scenes must not hit the frustum clamp (forward.cu:102-107) -- asserted.
+SURVEY.md Appendix A item 14: (i) straight-through 0.99 clamp; (ii) inside the frustum clamp of the EWA Jacobian
+(forward.cu:102-107) the clamped t.x / t.y are constants for the gradient -- no gradient into t.x (x_grad_mul,
+backward.cu:177-178, 265-266) and dJ02/dt.z taken with the clamped value held fixed (backward.cu:174-176); (iv) dL/dscale
+without the scale_modifier factor (backward.cu:281-345); (v) masks carry no gradient.
 """
 import numpy as np
 import torch
@@ -57,23 +59,29 @@ def render(o, means3D, scales, rotations, opacities, shs, scale_modifier=1.0):
     pix = torch.stack([((ndc[:, 0] + 1.0) * W - 1.0) * 0.5, ((ndc[:, 1] + 1.0) * H - 1.0) * 0.5], 1)
     vis = torch.from_numpy(o["radii"] > 0)
     tz = t[:, 2]
-    assert bool(((t[:, 0] / tz).abs()[vis] < 1.3 * tanx).all() and ((t[:, 1] / tz).abs()[vis] < 1.3 * tany).all()), \
-        "scene hits the frustum clamp; autograd would differ by design (Appendix A 14 ii)"
+    # Appendix A 14 (ii): where the clamp is active the reference uses lim * t.z as a CONSTANT in J
+    limx, limy = 1.3 * tanx, 1.3 * tany
+    in_x = ((t[:, 0] / tz).detach().abs() <= limx)
+    in_y = ((t[:, 1] / tz).detach().abs() <= limy)
+    tx = torch.where(in_x, t[:, 0], (torch.sign(t[:, 0]) * limx * tz).detach())
+    ty = torch.where(in_y, t[:, 1], (torch.sign(t[:, 1]) * limy * tz).detach())
+    clamp_active = int(((~in_x | ~in_y) & vis).sum())
     # Sigma = R S^2 R^T with the standard rotation of the (unnormalised) quaternion (forward.cu:146-180)
     r, x, y, z = rotations[:, 0], rotations[:, 1], rotations[:, 2], rotations[:, 3]
     Rm = torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y),
                       2 * (x * y + r * z), 1 - 2 * (x * x + z * z), 2 * (y * z - r * x),
                       2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y)], 1).reshape(P, 3, 3)
-    S = torch.diag_embed(scale_modifier * scales)
+    # Appendix A 14 (iv): value mod * s, derivative w.r.t. s taken as 1 (the reference omits the factor)
+    S = torch.diag_embed(scales + (scale_modifier - 1.0) * scales.detach())
     Mm = Rm @ S
     Sigma = Mm @ Mm.transpose(1, 2)
     # EWA: cov2D = (J W) Sigma (J W)^T + 0.3 I (forward.cu:84-140)
     Wm = V[:3, :3].t()                          # world -> view rotation
     J = torch.zeros(P, 2, 3, dtype=dt)
     J[:, 0, 0] = fx / tz
-    J[:, 0, 2] = -fx * t[:, 0] / (tz * tz)
+    J[:, 0, 2] = -fx * tx / (tz * tz)
     J[:, 1, 1] = fy / tz
-    J[:, 1, 2] = -fy * t[:, 1] / (tz * tz)
+    J[:, 1, 2] = -fy * ty / (tz * tz)
     JW = J @ Wm
     cov = JW @ Sigma @ JW.transpose(1, 2)
     a, b, c = cov[:, 0, 0] + 0.3, cov[:, 0, 1], cov[:, 1, 1] + 0.3
@@ -118,4 +126,5 @@ def render(o, means3D, scales, rotations, opacities, shs, scale_modifier=1.0):
     T_final = torch.prod(torch.where(valid, 1.0 - alpha, torch.ones_like(alpha)), dim=1)
     img = img + T_final[:, None] * bg[None]
     n_contrib = torch.where(valid.any(1), (valid.to(torch.int64) * torch.arange(1, valid.shape[1] + 1)).max(1).values, 0)
+    render.clamp_active = clamp_active   # how many visible Gaussians had the frustum clamp active (for the tests)
     return img.t().reshape(3, H, W), T_final, n_contrib
