@@ -39,10 +39,6 @@ KERNEL_SYMBOL = {"render_backward": "gsr_render_backward_wave_kernel", "render_f
 
 
 DOMINANT_STAGE = "render_backward"   # the kernel with the largest launch time in every configuration measured
-# share of transcendental instructions (v_exp_f32 / v_rcp_f32 / v_log_f32: 8 issue cycles instead of 4) among the VALU
-# instructions of the blend kernels' inner loops, counted in the ISA (used when the PMC summary has no
-# SQ_INSTS_VALU_TRANS_F32 for the kernel)
-TRANS_SHARE = {"render_backward": 0.065, "render_forward": 0.06}
 
 
 def _pmc_entry(stage, workload):
@@ -329,21 +325,19 @@ def step_stats(ms):
     return dict(min=round(ms[0], 4), median=round(med, 4), max=round(ms[-1], 4), n=n)
 
 
-def valu_issue_fraction(stage, workload, avg_ms):
-    """Fraction of the chip's VALU issue capacity the kernel used during its launch, from SQ_INSTS_VALU of the committed
-    PMC summary and the issue costs measured on MI355X with tools/valu_probe.hip (profiles/r2_valu_probe.txt): one
-    SIMD issues one wave64 VALU instruction per 4 cycles whatever the number of waves (3.85-4.3 measured; fma, pk_fma,
-    dpp, cndmask alike), a transcendental (v_exp/v_rcp/...) holds it for 8.  1024 SIMDs; clock = the kernel's own
-    (SQ_BUSY_CYCLES is summed over the 32 shader engines).  By construction <= 1."""
+def valu_issue_fraction(stage, workload):
+    """Fraction of the chip's VALU issue capacity the kernel used during its launch, from the committed PMC summary
+    (tools/profile_run.sh -> tools/pmc_summary.py): (4 * (SQ_INSTS_VALU - SQ_INSTS_VALU_TRANS_F32) + 8 * SQ_INSTS_VALU_TRANS_F32)
+    / (1024 SIMDs * SQ_BUSY_CYCLES / 32 shader engines).  Issue costs measured on MI355X with tools/valu_probe.hip
+    (profiles/r2_valu_probe.txt): one SIMD issues one wave64 VALU instruction per ~4 cycles whatever the number of resident
+    waves (fma, pk_fma, pk_mul, dpp, cndmask, cmp, max alike), a transcendental holds it for ~8.  Instruction counts and the
+    kernel's own cycle count come from the same PMC run, so no assumption about the clock enters."""
     try:
         e = _pmc_entry(stage, workload)
-        insts = e["SQ_INSTS_VALU"]
-        trans = e.get("SQ_INSTS_VALU_TRANS_F32", TRANS_SHARE.get(stage, 0.0) * insts)
-        clock_hz = e["SQ_BUSY_CYCLES"] / 32.0 / (e.get("kernel_ms", avg_ms) * 1e-3)
-        cycles = 4.0 * (insts - trans) + 8.0 * trans
-        return dict(frac=round(cycles / (1024.0 * avg_ms * 1e-3 * clock_hz), 3), clock_GHz=round(clock_hz / 1e9, 3),
-                    valu_insts=int(insts), transcendental_insts=int(trans), cycles_per_inst=4.0, cycles_per_transcendental=8.0,
-                    simds=1024, source=os.path.basename(PMC_SUMMARY))
+        return dict(frac=round(e["valu_issue_frac"], 3), clock_GHz=round(e["clock_GHz"], 3), valu_insts=int(e["SQ_INSTS_VALU"]),
+                    transcendental_insts=int(e.get("SQ_INSTS_VALU_TRANS_F32", 0)), cycles_per_inst=4.0,
+                    cycles_per_transcendental=8.0, simds=1024, avg_waves_per_simd=round(e.get("avg_waves_per_simd", 0.0), 2),
+                    source=os.path.basename(PMC_SUMMARY))
     except (OSError, KeyError, ValueError, ZeroDivisionError):
         return None
 
@@ -564,7 +558,7 @@ def run_rank(args, rank, world, dev):
         a = kern[dom]["GBps"] or 0.0
         roofline = dict(kernel=dom, bound="hbm", achieved=a, peak=HBM_PEAK_GBS, unit="GB/s",
                         frac=round(a / HBM_PEAK_GBS, 4), traffic=pmc_traffic(dom, args.config),
-                        valu_issue=valu_issue_fraction(dom, args.config, kern[dom]["ms"]),
+                        valu_issue=valu_issue_fraction(dom, args.config),
                         note="this kernel is bound by VALU issue, not by HBM (see valu_issue: share of the 1024 SIMDs' issue "
                              "cycles its instructions occupy), so its HBM fraction is small by construction; 'kernels' "
                              "lists the streaming stages with their own HBM fractions",

@@ -156,6 +156,7 @@ extern "C" int gsr_geometry_layout_of(int P, gsr_geometry_layout* o)
 	o->rect = off;           off = gsr_align_up(off + n * 8);
 	o->slot_base = off;      off = gsr_align_up(off + n * 4);
 	o->clamped = off;        off = gsr_align_up(off + n);
+	o->sh_ddir = off;        off = gsr_align_up(off + n * 36);
 	o->status = off;         off = gsr_align_up(off + GSR_STATUS_WORDS * 4);
 	o->scan_temp = off;      off = gsr_align_up(off + 2 * gsr_align_up(nb * 4));
 	o->sort_table = off;     off = gsr_align_up(off + gsr_radix_table_bytes(n));
@@ -230,6 +231,7 @@ GsrGeometry gsr_geometry_view(void* blob, int P)
 	g.rect = (uint2*)(b + l.rect);
 	g.slot_base = (uint32_t*)(b + l.slot_base);
 	g.clamped = (uint8_t*)(b + l.clamped);
+	g.sh_ddir = (float*)(b + l.sh_ddir);
 	g.status = (uint32_t*)(b + l.status);
 	g.block_sums = (uint32_t*)(b + l.scan_temp);
 	g.sorted_block_sums = (uint32_t*)(b + l.scan_temp + gsr_align_up(nb * 4));

@@ -48,9 +48,10 @@ __device__ __forceinline__ void gsr_sh_basis(int deg, float x, float y, float z,
 }
 
 // backward.cu:20-139.  dL_dRGB = dL_dcolor with clamped channels zeroed (returned in dL_dRGB_out).
-// write_dsh: writes dL_dsh rows [0, (D+1)^2) and zeros the rest up to M; otherwise only the
+// ddir9: d(colour channel)/d(unit direction) as the forward kernel left it (gsr_sh_dcolor_ddir): the SH row itself is
+// not needed here.  write_dsh: writes dL_dsh rows [0, (D+1)^2) and zeros the rest up to M; otherwise only the
 // view-direction term of dL_dmean is produced (view-parallel mode, see gsr_sh_grad_from_views).
-__device__ __forceinline__ void gsr_sh_backward(int deg, int M, GsrVec3 pos, const float* campos, const float* sh,
+__device__ __forceinline__ void gsr_sh_backward(int deg, int M, GsrVec3 pos, const float* campos, const float* ddir9,
                                                 uint8_t clamp_bits, const float* dL_dcolor, float* dL_dmean,
                                                 float* dL_dsh, bool write_dsh, float* dL_dRGB_out, float* basis_out = nullptr)
 {
@@ -60,49 +61,22 @@ __device__ __forceinline__ void gsr_sh_backward(int deg, int M, GsrVec3 pos, con
 	float dd0 = 0.f, dd1 = 0.f, dd2 = 0.f;
 	const int used = (deg + 1) * (deg + 1);
 	float basis[16];
-	gsr_sh_basis(deg, x, y, z, basis);
+	if (write_dsh || basis_out) gsr_sh_basis(deg, x, y, z, basis);
 	if (basis_out) {
 #pragma unroll
 		for (int k = 0; k < 16; k++) basis_out[k] = (k < used) ? basis[k] : 0.f;  // entries >= used are never set by gsr_sh_basis
 	}
 #pragma unroll
 	for (int ch = 0; ch < 3; ch++) {
-#define SH(k) sh[(k) * 3 + ch]
 		const float g = dL_dcolor[ch] * (((clamp_bits >> ch) & 1) ? 0.f : 1.f);
 		dL_dRGB_out[ch] = g;
-		float dRGBdx = 0, dRGBdy = 0, dRGBdz = 0;
 		if (write_dsh) {
 #pragma unroll
 			for (int k = 0; k < 16; k++)
 				if (k < used) dL_dsh[k * 3 + ch] = basis[k] * g;
 			for (int k = used; k < M; k++) dL_dsh[k * 3 + ch] = 0.f;
 		}
-		if (deg > 0) {
-			dRGBdx = -GSR_SH_C1 * SH(3);
-			dRGBdy = -GSR_SH_C1 * SH(1);
-			dRGBdz = GSR_SH_C1 * SH(2);
-			if (deg > 1) {
-				float xx = x * x, yy = y * y, zz = z * z;
-				float xy = x * y, yz = y * z, xz = x * z;
-				dRGBdx += GSR_SH_C2[0] * y * SH(4) + GSR_SH_C2[2] * 2.f * -x * SH(6) + GSR_SH_C2[3] * z * SH(7) + GSR_SH_C2[4] * 2.f * x * SH(8);
-				dRGBdy += GSR_SH_C2[0] * x * SH(4) + GSR_SH_C2[1] * z * SH(5) + GSR_SH_C2[2] * 2.f * -y * SH(6) + GSR_SH_C2[4] * 2.f * -y * SH(8);
-				dRGBdz += GSR_SH_C2[1] * y * SH(5) + GSR_SH_C2[2] * 2.f * 2.f * z * SH(6) + GSR_SH_C2[3] * x * SH(7);
-				if (deg > 2) {
-					dRGBdx += (GSR_SH_C3[0] * SH(9) * 3.f * 2.f * xy + GSR_SH_C3[1] * SH(10) * yz + GSR_SH_C3[2] * SH(11) * -2.f * xy +
-					           GSR_SH_C3[3] * SH(12) * -3.f * 2.f * xz + GSR_SH_C3[4] * SH(13) * (-3.f * xx + 4.f * zz - yy) +
-					           GSR_SH_C3[5] * SH(14) * 2.f * xz + GSR_SH_C3[6] * SH(15) * 3.f * (xx - yy));
-					dRGBdy += (GSR_SH_C3[0] * SH(9) * 3.f * (xx - yy) + GSR_SH_C3[1] * SH(10) * xz +
-					           GSR_SH_C3[2] * SH(11) * (-3.f * yy + 4.f * zz - xx) + GSR_SH_C3[3] * SH(12) * -3.f * 2.f * yz +
-					           GSR_SH_C3[4] * SH(13) * -2.f * xy + GSR_SH_C3[5] * SH(14) * -2.f * yz +
-					           GSR_SH_C3[6] * SH(15) * -3.f * 2.f * xy);
-					dRGBdz += (GSR_SH_C3[1] * SH(10) * xy + GSR_SH_C3[2] * SH(11) * 4.f * 2.f * yz +
-					           GSR_SH_C3[3] * SH(12) * 3.f * (2.f * zz - xx - yy) + GSR_SH_C3[4] * SH(13) * 4.f * 2.f * xz +
-					           GSR_SH_C3[5] * SH(14) * (xx - yy));
-				}
-			}
-		}
-#undef SH
-		dd0 += dRGBdx * g; dd1 += dRGBdy * g; dd2 += dRGBdz * g;
+		dd0 += ddir9[3 * ch] * g; dd1 += ddir9[3 * ch + 1] * g; dd2 += ddir9[3 * ch + 2] * g;
 	}
 	GsrVec3 ddir = {dd0, dd1, dd2};
 	GsrVec3 dm = gsr_dnormvdv(dir_orig, ddir);
@@ -170,7 +144,9 @@ __device__ __forceinline__ void gsr_add_slot(const GsrGradSlot* __restrict__ slo
 template <bool LEAF>
 __global__ void __launch_bounds__(GSR_GB_THREADS) gsr_gaussian_backward_kernel(GsrGaussianBackwardArgs a, int sh_via_lds, int skip_dsh)
 {
-	__shared__ float4 s_sh[GSR_GB_THREADS / 64][64 * GSR_SH_ROW4];
+	// staging of the dL/dsh output block: rows of 13 float4; the packed layout goes out in two halves of 32 rows
+	// (6.6 KB per wave), the split leaf tensors as one linear 12 KB block
+	__shared__ float4 s_sh[GSR_GB_THREADS / 64][(LEAF ? 64 : 32) * GSR_SH_ROW4];
 	// the launch covers the Gaussians [first, first + count): the whole scene, or one part of it when the caller
 	// pipelines the gradient exchange of a finished part under the kernel of the next (gsr_backward_gaussians)
 	const int idx = a.first + blockIdx.x * GSR_GB_THREADS + threadIdx.x;
@@ -180,12 +156,14 @@ __global__ void __launch_bounds__(GSR_GB_THREADS) gsr_gaussian_backward_kernel(G
 	const bool in_range = idx < end;
 	// ---- (A) the Gaussian's own inputs, unconditionally for every Gaussian of the range: issued first, so that the
 	//      three dependent steps below (these -> slot validity bytes -> slot records) are the only memory round
-	//      trips of the wave (the SH block of (B) travels beside them)
+	//      trips of the wave.  The SH row is NOT among them: the forward left the nine derivatives the backward needs
+	//      (GsrGeometry::sh_ddir), so LDS only stages the dL/dsh OUTPUT block.
 	uint32_t tiles = 0, base = 0;
 	int radius = 0;
 	GsrVec3 mean = {0.f, 0.f, 0.f};
 	float sc[3] = {0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f}, cov_in[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 	uint8_t clamp_bits = 0;
+	float ddir9[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 	float leaf_opacity = 0.f;
 	if (in_range) {
 		tiles = a.g.tiles_touched[idx];
@@ -199,18 +177,16 @@ __global__ void __launch_bounds__(GSR_GB_THREADS) gsr_gaussian_backward_kernel(G
 			sc[0] = a.scales[3 * idx]; sc[1] = a.scales[3 * idx + 1]; sc[2] = a.scales[3 * idx + 2];
 			q[0] = a.rotations[4 * idx]; q[1] = a.rotations[4 * idx + 1]; q[2] = a.rotations[4 * idx + 2]; q[3] = a.rotations[4 * idx + 3];
 		}
-		if (a.shs) clamp_bits = a.g.clamped[idx];
+		if (a.shs) {
+			clamp_bits = a.g.clamped[idx];
+#pragma unroll
+			for (int k = 0; k < 9; k++) ddir9[k] = a.g.sh_ddir[(size_t)k * a.P + idx];  // nine planes; garbage for culled Gaussians: unused
+		}
 		if (LEAF) leaf_opacity = a.g.splat[idx].opacity;
 	}
 	const int wave_first = a.first + blockIdx.x * GSR_GB_THREADS + wave * 64;
 	const int nrows = min(64, end - wave_first);  // Gaussians of this wave (<= 0: none)
 
-	// ---- (B) the wave's SH block (64 x 48 floats, contiguous in HBM): coalesced loads now, into LDS at (D) ----
-	float4 shv4[12];
-	if (sh_via_lds && nrows > 0) {
-		if (LEAF) gsr_sh_lin_load(reinterpret_cast<float*>(s_sh[wave]), a.shs, a.shs_rest, wave_first, nrows, lane);
-		else gsr_sh_rows_fetch(shv4, a.shs, wave_first, nrows, lane);
-	}
 	// radii > 0 <=> tiles_touched > 0 (forward.cu:300-301 zeroes both together; culled: slot_base was never written)
 	const bool visible = in_range && (a.radii ? radius > 0 : tiles > 0);
 	if (!visible) tiles = 0;
@@ -224,9 +200,6 @@ __global__ void __launch_bounds__(GSR_GB_THREADS) gsr_gaussian_backward_kernel(G
 #pragma unroll
 		for (int j = 0; j < GSR_SLOT_COOP; j++) vmask |= vb[j] ? (1u << j) : 0u;
 	}
-	// ---- (D) SH block into LDS ----
-	if (!LEAF && sh_via_lds && nrows > 0) gsr_sh_rows_commit(s_sh[wave], shv4, nrows, lane);
-
 	// ---- (E) fixed-order sum of this Gaussian's (Gaussian,tile) slots ----
 	float acc[GSR_NACC];
 #pragma unroll
@@ -277,9 +250,12 @@ __global__ void __launch_bounds__(GSR_GB_THREADS) gsr_gaussian_backward_kernel(G
 	const size_t orow = (size_t)(idx - a.out_row0);
 	const int out_wave_first = wave_first - a.out_row0;
 	float* dsh_global = (!LEAF && a.dL_dsh && in_range) ? a.dL_dsh + orow * M * 3 : nullptr;
-	float sh_local[48], dsh_local[48];  // LEAF without the LDS path: gathered rows / their gradient
+	float dsh_local[48];  // LEAF without the LDS path: the row of the feature gradient
 	float q_raw[4] = {0.f, 0.f, 0.f, 0.f}, q_den = 1.f;
 	float dRGB[3] = {0.f, 0.f, 0.f};  // dL/dcolor with the channels clamped by the forward zeroed
+	float basis_keep[16];             // SH basis at the view direction (entries >= (D+1)^2 zero), visible Gaussians
+#pragma unroll
+	for (int k = 0; k < 16; k++) basis_keep[k] = 0.f;
 
 	if (visible) {
 		// ---- computeCov2DCUDA, backward.cu:144-277 ----
@@ -356,48 +332,23 @@ __global__ void __launch_bounds__(GSR_GB_THREADS) gsr_gaussian_backward_kernel(G
 
 		if (a.shs) {
 			if (sh_via_lds) {
-				float shv[48];  // own row out of LDS into registers, then dL_dsh overwrites the row in place
-				if (LEAF) {
-					gsr_sh_lin_row_get(reinterpret_cast<const float*>(s_sh[wave]), lane, shv);
-				} else {
-					gsr_sh_row_get(s_sh[wave], lane, shv);
-				}
-				// dL_dsh = basis x dL/dRGB is written below as 12 float4 (the row is conflict-free for 16-byte
-				// accesses; 48 scalar stores at this row stride hit 4-way bank conflicts)
-				float basis[16];
-				const int used_sh = (a.D + 1) * (a.D + 1);
-				gsr_sh_backward(a.D, M, mean, a.cam_pos, shv, clamp_bits, dcolor, dmean3D, nullptr, false, dRGB, basis);
+				// dL_dsh = basis x dL/dRGB: kept as its two factors until the block store below
+				gsr_sh_backward(a.D, M, mean, a.cam_pos, ddir9, clamp_bits, dcolor, dmean3D, nullptr, false, dRGB, basis_keep);
 				if (!skip_dsh && LEAF) {
+					const int used_sh = (a.D + 1) * (a.D + 1);
 					float o[48];
 #pragma unroll
-					for (int e = 0; e < 48; e++) o[e] = (e / 3 < used_sh) ? basis[e / 3] * dRGB[e % 3] : 0.f;
+					for (int e = 0; e < 48; e++) o[e] = (e / 3 < used_sh) ? basis_keep[e / 3] * dRGB[e % 3] : 0.f;
 					gsr_sh_lin_row_put(reinterpret_cast<float*>(s_sh[wave]), lane, o);
-				} else if (!skip_dsh) {
-#pragma unroll
-					for (int j = 0; j < 12; j++) {
-						float o[4];
-#pragma unroll
-						for (int t = 0; t < 4; t++)  // rows >= (D+1)^2 are +0, not the -0 a product with a negative gradient would give
-							o[t] = ((4 * j + t) / 3 < used_sh) ? basis[(4 * j + t) / 3] * dRGB[(4 * j + t) % 3] : 0.f;
-						s_sh[wave][lane * GSR_SH_ROW4 + j] = make_float4(o[0], o[1], o[2], o[3]);
-					}
 				}
 			} else if (LEAF) {
 				const int used = (a.D + 1) * (a.D + 1);
-#pragma unroll
-				for (int k = 0; k < 16; k++)  // constant indices (registers, no scratch); (D+1)^2 <= 16
-					if (k < used) {
-#pragma unroll
-						for (int ch = 0; ch < 3; ch++)
-							sh_local[k * 3 + ch] = k == 0 ? a.shs[3 * (size_t)idx + ch] : a.shs_rest[((size_t)idx * (M - 1) + (k - 1)) * 3 + ch];
-					}
 				float basis[16];
-				gsr_sh_backward(a.D, used, mean, a.cam_pos, sh_local, clamp_bits, dcolor, dmean3D, nullptr, false, dRGB, basis);
+				gsr_sh_backward(a.D, used, mean, a.cam_pos, ddir9, clamp_bits, dcolor, dmean3D, nullptr, false, dRGB, basis);
 #pragma unroll
 				for (int e = 0; e < 48; e++) dsh_local[e] = (e / 3 < used) ? basis[e / 3] * dRGB[e % 3] : 0.f;
 			} else {
-				gsr_sh_backward(a.D, M, mean, a.cam_pos, a.shs + (size_t)idx * M * 3, clamp_bits, dcolor, dmean3D, dsh_global,
-				                !skip_dsh, dRGB);
+				gsr_sh_backward(a.D, M, mean, a.cam_pos, ddir9, clamp_bits, dcolor, dmean3D, dsh_global, !skip_dsh, dRGB);
 			}
 		}
 		if (a.scales)
@@ -421,22 +372,34 @@ __global__ void __launch_bounds__(GSR_GB_THREADS) gsr_gaussian_backward_kernel(G
 	if (skip_dsh) {
 		// view-parallel mode: no SH gradient here; dL_dcolor carries the clamp-masked dL/dRGB instead
 		dcolor[0] = dRGB[0]; dcolor[1] = dRGB[1]; dcolor[2] = dRGB[2];
-	} else if (sh_via_lds) {
+	} else if (sh_via_lds && LEAF) {
 		if (!visible) {
-			if (LEAF) {
-				float z[48];
+			float z[48];
 #pragma unroll
-				for (int e = 0; e < 48; e++) z[e] = 0.f;
-				gsr_sh_lin_row_put(reinterpret_cast<float*>(s_sh[wave]), lane, z);
-			} else {
-#pragma unroll
-				for (int j = 0; j < 12; j++) s_sh[wave][lane * GSR_SH_ROW4 + j] = make_float4(0.f, 0.f, 0.f, 0.f);
-			}
+			for (int e = 0; e < 48; e++) z[e] = 0.f;
+			gsr_sh_lin_row_put(reinterpret_cast<float*>(s_sh[wave]), lane, z);
 		}
 		__builtin_amdgcn_wave_barrier();
-		if (nrows > 0) {
-			if (LEAF) gsr_sh_lin_store(reinterpret_cast<const float*>(s_sh[wave]), a.dL_dsh, a.dL_dsh_rest, out_wave_first, nrows, lane);
-			else gsr_sh_rows_store(s_sh[wave], a.dL_dsh, out_wave_first, nrows, lane);
+		if (nrows > 0) gsr_sh_lin_store(reinterpret_cast<const float*>(s_sh[wave]), a.dL_dsh, a.dL_dsh_rest, out_wave_first, nrows, lane);
+	} else if (sh_via_lds) {
+		// packed (P,16,3) output: each half of the wave writes its rows (12 conflict-free float4 per lane; zeros for culled
+		// Gaussians, +0 for the rows >= (D+1)^2), then the whole wave streams the half out with coalesced 16-byte stores
+		const int used_sh = visible ? (a.D + 1) * (a.D + 1) : 0;
+#pragma unroll
+		for (int half = 0; half < 2; half++) {
+			if ((lane >> 5) == half) {
+#pragma unroll
+				for (int j = 0; j < 12; j++) {
+					float o[4];
+#pragma unroll
+					for (int t = 0; t < 4; t++)
+						o[t] = ((4 * j + t) / 3 < used_sh) ? basis_keep[(4 * j + t) / 3] * dRGB[(4 * j + t) % 3] : 0.f;
+					s_sh[wave][(lane & 31) * GSR_SH_ROW4 + j] = make_float4(o[0], o[1], o[2], o[3]);
+				}
+			}
+			__builtin_amdgcn_wave_barrier();
+			if (nrows > 32 * half) gsr_sh_rows_store_half(s_sh[wave], a.dL_dsh, out_wave_first, nrows, lane, half);
+			__builtin_amdgcn_wave_barrier();
 		}
 	} else if (LEAF) {
 		if (in_range) {

@@ -192,6 +192,16 @@ __device__ __forceinline__ void gsr_sh_rows_commit(float4* __restrict__ rows, co
 		if (row < nrows) rows[row * GSR_SH_ROW4 + col] = v[it];
 	}
 }
+// one half of the fetched block (v[6 * half .. 6 * half + 5] = rows 32 * half .. 32 * half + 31) into LDS rows 0 .. 31
+__device__ __forceinline__ void gsr_sh_rows_commit_half(float4* __restrict__ rows, const float4* __restrict__ v, int nrows, int lane, int half)
+{
+	const int e = lane & 3, r0 = gsr_sh_rowmap_store(lane >> 2);
+#pragma unroll
+	for (int it = 0; it < 6; it++) {
+		const int lrow = 16 * (it / 3) + r0, col = 4 * (it % 3) + e;
+		if (32 * half + lrow < nrows) rows[lrow * GSR_SH_ROW4 + col] = v[6 * half + it];
+	}
+}
 __device__ __forceinline__ void gsr_sh_rows_load(float4* __restrict__ rows, const float* __restrict__ shs, int wave_first, int nrows, int lane)
 {
 	float4 v[12];
@@ -206,6 +216,18 @@ __device__ __forceinline__ void gsr_sh_rows_store(const float4* __restrict__ row
 	for (int it = 0; it < 12; it++) {
 		const int row = 16 * (it / 3) + r0, col = 4 * (it % 3) + e;
 		if (row < nrows) dst[row * 12 + col] = rows[row * GSR_SH_ROW4 + col];
+	}
+}
+// One half of the wave's block (rows 32 * half .. 32 * half + 31, staged at LDS rows 0 .. 31): six wave instructions.
+// Staging the output in two halves halves the LDS a wave holds (6.6 KB: 4 waves per SIMD fit beside the registers).
+__device__ __forceinline__ void gsr_sh_rows_store_half(const float4* __restrict__ rows, float* __restrict__ dst_shs, int wave_first, int nrows, int lane, int half)
+{
+	float4* dst = reinterpret_cast<float4*>(dst_shs + (size_t)wave_first * 48);
+	const int e = lane & 3, r0 = gsr_sh_rowmap_load(lane >> 2);
+#pragma unroll
+	for (int it = 0; it < 6; it++) {
+		const int lrow = 16 * (it / 3) + r0, row = 32 * half + lrow, col = 4 * (it % 3) + e;
+		if (row < nrows) dst[row * 12 + col] = rows[lrow * GSR_SH_ROW4 + col];
 	}
 }
 // the lane's own 48 coefficients out of / into its row
@@ -282,6 +304,40 @@ __device__ __forceinline__ void gsr_sh_lin_row_put(float* __restrict__ lin, int 
 	for (int c = 0; c < 3; c++) lin[GSR_SH_LIN_DC + 3 * lane + c] = row48[c];
 #pragma unroll
 	for (int j = 0; j < 45; j++) lin[45 * lane + j] = row48[3 + j];
+}
+
+// d(colour channel c) / d(unit view direction), c = 0..2: the nine sums of backward.cu:98-132, evaluated by the FORWARD
+// kernel while the Gaussian's SH row is in registers and kept (GsrGeometry::sh_ddir) for the backward, which then never
+// reads the 192-byte SH row again.  Written as sum_k (d basis_k / d{x,y,z}) * sh[k][c] with the 33 non-zero basis
+// derivatives formed once and explicit FMAs (the reference multiplies each term out per channel: 3x the
+// instructions; the two differ by fp32 rounding only, ~1e-7 relative, far inside the gradient bars).
+__device__ __forceinline__ void gsr_sh_ddir9(int deg, const float* sh, float x, float y, float z, float* d9)
+{
+#pragma unroll
+	for (int i = 0; i < 9; i++) d9[i] = 0.f;
+	if (deg < 1) return;
+#define ACC(comp, coef, k)                                                                 \
+	d9[comp] = __builtin_fmaf((coef), sh[(k) * 3], d9[comp]);                              \
+	d9[3 + comp] = __builtin_fmaf((coef), sh[(k) * 3 + 1], d9[3 + comp]);                  \
+	d9[6 + comp] = __builtin_fmaf((coef), sh[(k) * 3 + 2], d9[6 + comp]);
+	ACC(0, -GSR_SH_C1, 3) ACC(1, -GSR_SH_C1, 1) ACC(2, GSR_SH_C1, 2)
+	if (deg > 1) {
+		ACC(0, GSR_SH_C2[0] * y, 4) ACC(0, GSR_SH_C2[2] * -2.f * x, 6) ACC(0, GSR_SH_C2[3] * z, 7) ACC(0, GSR_SH_C2[4] * 2.f * x, 8)
+		ACC(1, GSR_SH_C2[0] * x, 4) ACC(1, GSR_SH_C2[1] * z, 5) ACC(1, GSR_SH_C2[2] * -2.f * y, 6) ACC(1, GSR_SH_C2[4] * -2.f * y, 8)
+		ACC(2, GSR_SH_C2[1] * y, 5) ACC(2, GSR_SH_C2[2] * 4.f * z, 6) ACC(2, GSR_SH_C2[3] * x, 7)
+		if (deg > 2) {
+			const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+			ACC(0, GSR_SH_C3[0] * 6.f * xy, 9) ACC(0, GSR_SH_C3[1] * yz, 10) ACC(0, GSR_SH_C3[2] * -2.f * xy, 11)
+			ACC(0, GSR_SH_C3[3] * -6.f * xz, 12) ACC(0, GSR_SH_C3[4] * (-3.f * xx + 4.f * zz - yy), 13) ACC(0, GSR_SH_C3[5] * 2.f * xz, 14)
+			ACC(0, GSR_SH_C3[6] * 3.f * (xx - yy), 15)
+			ACC(1, GSR_SH_C3[0] * 3.f * (xx - yy), 9) ACC(1, GSR_SH_C3[1] * xz, 10) ACC(1, GSR_SH_C3[2] * (-3.f * yy + 4.f * zz - xx), 11)
+			ACC(1, GSR_SH_C3[3] * -6.f * yz, 12) ACC(1, GSR_SH_C3[4] * -2.f * xy, 13) ACC(1, GSR_SH_C3[5] * -2.f * yz, 14)
+			ACC(1, GSR_SH_C3[6] * -6.f * xy, 15)
+			ACC(2, GSR_SH_C3[1] * xy, 10) ACC(2, GSR_SH_C3[2] * 8.f * yz, 11) ACC(2, GSR_SH_C3[3] * 3.f * (2.f * zz - xx - yy), 12)
+			ACC(2, GSR_SH_C3[4] * 8.f * xz, 13) ACC(2, GSR_SH_C3[5] * (xx - yy), 14)
+		}
+	}
+#undef ACC
 }
 
 // forward.cu:84-140 computeCov2D, also recomputed by backward.cu:144-199

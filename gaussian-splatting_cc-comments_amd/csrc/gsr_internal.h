@@ -34,6 +34,7 @@ struct GsrGeometry {
 	uint2* rect;               // dense copy of the tile rectangle {x | y << 16, w | h << 16}: what the depth-ordered kernels gather
 	uint32_t* slot_base;       // first (Gaussian,tile) gradient slot = offset of the Gaussian's first instance in depth-ordered emission
 	uint8_t* clamped;
+	float* sh_ddir;            // [9][P] d(colour channel c)/d(unit view direction) of the visible Gaussians (plane 3c + {x,y,z})
 	uint32_t* status;             // GSR_STATUS_* words
 
 	uint32_t* block_sums;         // (unused since the instance count moved into the status words)

@@ -37,7 +37,9 @@ __device__ __forceinline__ float gsr_sh_channel(int deg, const float* sh, int ch
 template <bool LEAF>
 __global__ void __launch_bounds__(GSR_PREPROCESS_BLOCK) gsr_preprocess_kernel(GsrPreprocessArgs a, int sh_via_lds, uint32_t* __restrict__ clear, size_t clear_words)
 {
-	__shared__ float4 s_sh[GSR_PREPROCESS_BLOCK / 64][64 * GSR_SH_ROW4];
+	// staging of the wave's SH block: the packed layout passes through in two halves of 32 rows (6.6 KB per wave, so that
+	// 4 waves per SIMD fit), the split leaf tensors as one linear 12 KB block
+	__shared__ float4 s_sh[GSR_PREPROCESS_BLOCK / 64][(LEAF ? 64 : 32) * GSR_SH_ROW4];
 	const int idx = blockIdx.x * GSR_PREPROCESS_BLOCK + threadIdx.x;
 	// The Gaussian's own inputs first, unconditionally (a culled Gaussian wastes 44 bytes): issued ahead of the SH
 	// block, every load of the wave is in flight at once -- one memory round trip instead of three dependent ones
@@ -59,15 +61,26 @@ __global__ void __launch_bounds__(GSR_PREPROCESS_BLOCK) gsr_preprocess_kernel(Gs
 	}
 	// The wave's 64 x 48 SH floats are contiguous in HBM: stage them into LDS with coalesced float4
 	// loads (a lane reading its own 192-byte row makes every load instruction touch 64 lines)
+	float row[48];  // the lane's own SH row (registers: only ever indexed with constants)
 	if (sh_via_lds) {
 		const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 		const int wave_first = blockIdx.x * GSR_PREPROCESS_BLOCK + wave * 64;
 		const int nrows = min(64, a.P - wave_first);
-		if (nrows > 0) {
-			if (LEAF) gsr_sh_lin_load(reinterpret_cast<float*>(s_sh[wave]), a.shs, a.shs_rest, wave_first, nrows, lane);
-			else gsr_sh_rows_load(s_sh[wave], a.shs, wave_first, nrows, lane);
+		if (LEAF) {
+			if (nrows > 0) gsr_sh_lin_load(reinterpret_cast<float*>(s_sh[wave]), a.shs, a.shs_rest, wave_first, nrows, lane);
+			__builtin_amdgcn_wave_barrier();
+			gsr_sh_lin_row_get(reinterpret_cast<const float*>(s_sh[wave]), lane, row);
+		} else {
+			float4 v[12];
+			gsr_sh_rows_fetch(v, a.shs, wave_first, max(nrows, 0), lane);  // all twelve loads in flight at once
+#pragma unroll
+			for (int half = 0; half < 2; half++) {
+				gsr_sh_rows_commit_half(s_sh[wave], v, nrows, lane, half);
+				__builtin_amdgcn_wave_barrier();
+				if ((lane >> 5) == half) gsr_sh_row_get(s_sh[wave], lane & 31, row);
+				__builtin_amdgcn_wave_barrier();
+			}
 		}
-		__builtin_amdgcn_wave_barrier();
 	}
 	uint32_t tiles = 0;
 	uint2 rect = make_uint2(0u, 0u);
@@ -126,14 +139,11 @@ __global__ void __launch_bounds__(GSR_PREPROCESS_BLOCK) gsr_preprocess_kernel(Gs
 				float len = sqrtf(dx * dx + dy * dy + dz * dz);
 				dx = dx / len; dy = dy / len; dz = dz / len;
 				const float* sh = a.shs + (size_t)idx * a.M * 3;
-				float raw[3];
+				float raw[3], ddir9[9];
 				if (sh_via_lds) {
-					// own row into registers: only ever indexed with constants below, so it never touches scratch
-					float row[48];
-					if (LEAF) gsr_sh_lin_row_get(reinterpret_cast<const float*>(s_sh[threadIdx.x >> 6]), threadIdx.x & 63, row);
-					else gsr_sh_row_get(s_sh[threadIdx.x >> 6], threadIdx.x & 63, row);
 #pragma unroll
 					for (int ch = 0; ch < 3; ch++) raw[ch] = gsr_sh_channel(a.D, row, ch, dx, dy, dz);
+					gsr_sh_ddir9(a.D, row, dx, dy, dz, ddir9);
 				} else {
 					float sh_local[48];
 					if (LEAF) {  // generic M / unaligned leaves: gather the used rows (rare path)
@@ -149,7 +159,11 @@ __global__ void __launch_bounds__(GSR_PREPROCESS_BLOCK) gsr_preprocess_kernel(Gs
 					}
 #pragma unroll
 					for (int ch = 0; ch < 3; ch++) raw[ch] = gsr_sh_channel(a.D, sh, ch, dx, dy, dz);
+					gsr_sh_ddir9(a.D, sh, dx, dy, dz, ddir9);
 				}
+				// what the backward needs from the SH row, so that it never reads the row again (36 B instead of 192 B)
+#pragma unroll
+				for (int k = 0; k < 9; k++) a.g.sh_ddir[(size_t)k * a.P + idx] = ddir9[k];  // nine planes: each store instruction is one contiguous run
 #pragma unroll
 				for (int ch = 0; ch < 3; ch++) {
 					const float v = raw[ch];

@@ -28,7 +28,7 @@ _sz = ctypes.c_size_t
 
 class GeometryLayout(ctypes.Structure):
     _fields_ = [(n, _sz) for n in ("splat", "depth_keys", "depth_keys_alt", "perm", "perm_alt", "tiles_touched", "rect",
-                                   "slot_base", "clamped", "status", "scan_temp", "sort_table", "total")]
+                                   "slot_base", "clamped", "sh_ddir", "status", "scan_temp", "sort_table", "total")]
 
 
 class ImageLayout(ctypes.Structure):

@@ -64,6 +64,8 @@ typedef struct {
 	size_t rect;           /* [P] uint2: tile rectangle {min x | min y << 16, width | height << 16} (dense copy of the record's) */
 	size_t slot_base;      /* [P] u32: first gradient slot of the Gaussian = offset of its first instance in depth-ordered emission */
 	size_t clamped;        /* [P] u8 bit c set = colour channel c was clamped at 0 */
+	size_t sh_ddir;        /* [9][P] f32 d(colour channel c)/d(unit view direction x,y,z) of the visible Gaussians, left by the forward so
+	                          that the backward does not read the SH rows again (backward.cu:98-132) */
 	size_t status;         /* u32 device status words (0: prefiltered trap; 2: depth order in the _alt pair; 4..67: partial instance
 	                          counts; 68..131 / 132..195: partial maxima of ~depth key / depth key of the visible Gaussians) */
 	size_t scan_temp;      /* per-workgroup tile counts: original order, then depth order */
