@@ -331,7 +331,6 @@ static int gsr_forward_preprocess_impl(int P, int D, int M, int width, int heigh
 		gsr_launch_preprocess(a, s);
 	}
 	if ((rc = gsr_stage_done(s, debug, "preprocess"))) return rc;
-	const int nb = (P + GSR_PREPROCESS_BLOCK - 1) / GSR_PREPROCESS_BLOCK;
 
 	// read num_rendered back; the per-Gaussian half of the sort is enqueued behind the copy and keeps
 	// the GPU busy while the host waits on the event, allocates the binning buffer and launches stage 2
@@ -376,8 +375,7 @@ static int gsr_forward_preprocess_impl(int P, int D, int M, int width, int heigh
 		GsrProfScope p(s, "depth_sort");
 		if (fourth) gsr_radix_sort_passes(a.g.depth_keys, a.g.perm, a.g.depth_keys_alt, a.g.perm_alt, (size_t)P, 32, 4, 3, 1, a.g.sort_table, bias, s);
 		// three passes leave the order in (depth_keys_alt, perm_alt), four in (depth_keys, perm): recorded in status[2]
-		gsr_launch_sorted_block_sums(a.g, P, fourth ? 0 : 1, s);
-		gsr_launch_scan_block_sums(a.g.sorted_block_sums, nb, nullptr, s);
+		gsr_launch_sorted_block_sums(a.g, P, fourth ? 0 : 1, s);   // (their prefix sums are taken by the key emission itself)
 	}
 	return gsr_stage_done(s, debug, "depth_sort");
 }

@@ -119,8 +119,26 @@ __global__ void __launch_bounds__(GSR_PREPROCESS_BLOCK) gsr_duplicate_keys_kerne
 		tiles = w * (rc.y >> 16);      // = tiles_touched (0 for culled Gaussians)
 		if (!tiles) w = 1;
 	}
-	uint32_t total;
-	const uint32_t incl = gsr_block_incl_scan<GSR_PREPROCESS_BLOCK>(tiles, &total, lds) + g.sorted_block_sums[blockIdx.x];
+	// offset of this workgroup's first instance = sum of the tile counts of all workgroups in front of it (depth order):
+	// every workgroup adds those up itself (<= nb/256 coalesced loads per thread, all in flight together) -- cheaper than
+	// a scan kernel of its own between the depth sort and this one
+	uint32_t before = 0;
+	{
+		const uint32_t* __restrict__ sums = g.sorted_block_sums;
+		for (uint32_t b0 = 0; b0 < blockIdx.x; b0 += 8 * GSR_PREPROCESS_BLOCK) {
+			uint32_t t[8];
+#pragma unroll
+			for (int j = 0; j < 8; j++) {
+				const uint32_t b = b0 + j * GSR_PREPROCESS_BLOCK + threadIdx.x;
+				t[j] = b < blockIdx.x ? sums[b] : 0u;
+			}
+#pragma unroll
+			for (int j = 0; j < 8; j++) before += t[j];
+		}
+	}
+	uint32_t total, before_total;
+	(void)gsr_block_incl_scan<GSR_PREPROCESS_BLOCK>(before, &before_total, lds);
+	const uint32_t incl = gsr_block_incl_scan<GSR_PREPROCESS_BLOCK>(tiles, &total, lds) + before_total;
 	const uint32_t off = incl - tiles;
 	// the backward blend addresses its per-(Gaussian,tile) gradient slots with this; a 4-byte scatter into a dense
 	// 4*P-byte array that the caches absorb (into the 48-byte splat records it cost 2x write amplification)
