@@ -120,10 +120,10 @@ __device__ __forceinline__ void gsr_cov3d_backward(const float* scale, float mod
 }
 
 // Fixed-order sum of one Gaussian's contiguous run of per-tile gradient slots.  Runs of up to
-// GSR_SLOT_COOP slots are added by the owning lane; longer runs (a big splat can own > 1000) are
+// GSR_SLOT_COOP slots (a multiple of 6) are added by the owning lane; longer runs (a big splat can own > 1000) are
 // added by the whole wave, lanes striding over the run, then reduced with DPP -- so the wave's
 // time no longer follows its single most-loaded lane.  The order is fixed: bitwise reproducible.
-#define GSR_SLOT_COOP 12
+#define GSR_SLOT_COOP 18   // swept on MI355X at C3: 12 / 18 / 24 / 36 -> 0.172 / 0.164 / 0.166 / 0.171 ms
 #define GSR_NACC 9
 
 __device__ __forceinline__ void gsr_add_slot(const GsrGradSlot* __restrict__ slots, const uint8_t* __restrict__ valid,

@@ -10,9 +10,9 @@
 // reference's stable 64-bit sort -- but step 2 needs only ceil(bit / 8) passes over 8-byte pairs.
 //
 // One pass = two launches: per-block digit histogram -> scatter with an in-block stable ranking.  The histogram
-// kernel also adds each block's counts into per-CHUNK sums (a chunk = GSR_SORT_CHUNK consecutive blocks; one atomic
-// per digit per block, 64 adders per address), so the scatter kernel finds its block's offset inside a digit with
-// <= #chunks + GSR_SORT_CHUNK loads per thread and no scan kernel runs in between (it was 6 us x 6 passes per step).
+// kernel also adds each block's counts into per-CHUNK and per-SUPER-CHUNK sums (chunk = 64 consecutive blocks, super-chunk =
+// 64 chunks; two atomics per digit per block), so the scatter kernel finds its block's offset inside a digit with
+// <= #super-chunks + 63 + 63 loads per thread and no scan kernel runs in between (it was 6 us x 6 passes per step).
 // The ranking uses wave64 ballots ("which lanes hold my digit") instead of per-thread counters, so a lane's rank is
 // one popcount.
 // Keys may be biased: with a `bias` pointer the sort orders key' = key - min (culled keys 0xFFFFFFFF -> range + 1),
@@ -30,7 +30,7 @@
 #define GSR_SORT_ITEMS_LARGE 16
 #define GSR_SORT_ITEMS_SMALL 4
 #define GSR_SORT_SMALL_N (4u << 20)
-#define GSR_SORT_CHUNK 64   // blocks per chunk of the two-level offset table
+#define GSR_SORT_CHUNK 64   // blocks per chunk, chunks per super-chunk of the three-level offset table
 
 // min / range of the biased keys from the 64 + 64 partial maxima {max(~key)}, {max(key)} (GsrGeometry::status)
 struct GsrKeyBias { uint32_t min, culled; };  // culled = value that stands for 0xFFFFFFFF keys = (max - min) + 1
@@ -105,7 +105,13 @@ __global__ void __launch_bounds__(GSR_SORT_THREADS) gsr_radix_hist_kernel(const 
 	__syncthreads();
 	const uint32_t c = hist[threadIdx.x];
 	table[(size_t)blockIdx.x * GSR_SORT_RADIX + threadIdx.x] = c;  // [block][digit]: a block's row is one coalesced kilobyte
-	if (c) atomicAdd(&chunk_sums[(size_t)(blockIdx.x / GSR_SORT_CHUNK) * GSR_SORT_RADIX + threadIdx.x], c);  // [chunk][digit], zeroed beforehand
+	if (c) {  // [chunk][digit] and, behind them, [super-chunk][digit]: zeroed beforehand
+		atomicAdd(&chunk_sums[(size_t)(blockIdx.x / GSR_SORT_CHUNK) * GSR_SORT_RADIX + threadIdx.x], c);
+		// the third level only where the second alone would be long (> 64 chunks = 262 144 blocks' worth of elements / 64):
+		// its rows take 4 096 adders each (measured: +35 us per pass at 2 236 blocks when every block added to ONE row)
+		if (nchunks > GSR_SORT_CHUNK)
+			atomicAdd(&chunk_sums[(size_t)(nchunks + blockIdx.x / (GSR_SORT_CHUNK * GSR_SORT_CHUNK)) * GSR_SORT_RADIX + threadIdx.x], c);
+	}
 }
 
 template <int ITEMS>
@@ -143,15 +149,31 @@ __global__ void __launch_bounds__(GSR_SORT_THREADS) gsr_radix_scatter_kernel(
 	uint32_t my_gbase;
 	{
 		uint32_t v = 0, before = 0;
-		const int my_chunk = blockIdx.x / GSR_SORT_CHUNK;
-		// [chunk][digit] and [block][digit] rows: thread d reads word d of every row, so each load instruction of the
-		// workgroup fetches one contiguous kilobyte; 16 loads are in flight per group
-		for (int c0 = 0; c0 < nchunks; c0 += 16) {
+		const int my_chunk = blockIdx.x / GSR_SORT_CHUNK, my_super = my_chunk / GSR_SORT_CHUNK;
+		const int nsuper = (nchunks + GSR_SORT_CHUNK - 1) / GSR_SORT_CHUNK;
+		// [super][digit], [chunk][digit] and [block][digit] rows: thread d reads word d of every row, so each load instruction
+		// of the workgroup fetches one contiguous kilobyte; 16 loads are in flight per group.  Total of the digit = all
+		// super-chunks; in front of this block = earlier super-chunks + earlier chunks of its super-chunk + earlier blocks of
+		// its chunk: <= nsuper + 63 + 63 rows whatever the size of the sort
+		const uint32_t* super_sums = chunk_sums + (size_t)nchunks * GSR_SORT_RADIX;
+		const bool three_level = nchunks > GSR_SORT_CHUNK;  // uniform
+		if (three_level) {
+			for (int c0 = 0; c0 < nsuper; c0 += 16) {
+				uint32_t t[16];
+#pragma unroll
+				for (int j = 0; j < 16; j++) t[j] = (c0 + j < nsuper) ? super_sums[(size_t)(c0 + j) * GSR_SORT_RADIX + threadIdx.x] : 0u;
+#pragma unroll
+				for (int j = 0; j < 16; j++) { v += t[j]; before += (c0 + j < my_super) ? t[j] : 0u; }
+			}
+		}
+		// two levels: every chunk (total and the part in front); three levels: only the chunks of this super-chunk in front
+		const int c_first = three_level ? my_super * GSR_SORT_CHUNK : 0, c_end = three_level ? my_chunk : nchunks;
+		for (int c0 = c_first; c0 < c_end; c0 += 16) {
 			uint32_t t[16];
 #pragma unroll
-			for (int j = 0; j < 16; j++) t[j] = (c0 + j < nchunks) ? chunk_sums[(size_t)(c0 + j) * GSR_SORT_RADIX + threadIdx.x] : 0u;
+			for (int j = 0; j < 16; j++) t[j] = (c0 + j < c_end) ? chunk_sums[(size_t)(c0 + j) * GSR_SORT_RADIX + threadIdx.x] : 0u;
 #pragma unroll
-			for (int j = 0; j < 16; j++) { v += t[j]; before += (c0 + j < my_chunk) ? t[j] : 0u; }
+			for (int j = 0; j < 16; j++) { if (!three_level) v += t[j]; before += (c0 + j < my_chunk) ? t[j] : 0u; }
 		}
 		const int b0 = my_chunk * GSR_SORT_CHUNK, nb = (int)blockIdx.x - b0;  // blocks of this chunk in front of this one
 		for (int j0 = 0; j0 < nb; j0 += 16) {
@@ -255,10 +277,12 @@ int gsr_radix_num_passes(int nbits_total) { return (nbits_total + 7) / 8; }
 static inline int gsr_sort_items(size_t n) { return n <= GSR_SORT_SMALL_N ? GSR_SORT_ITEMS_SMALL : GSR_SORT_ITEMS_LARGE; }
 static inline size_t gsr_sort_nblocks(size_t n) { const size_t tile = (size_t)GSR_SORT_THREADS * gsr_sort_items(n); return (n + tile - 1) / tile; }
 static inline size_t gsr_sort_nchunks(size_t n) { return (gsr_sort_nblocks(n) + GSR_SORT_CHUNK - 1) / GSR_SORT_CHUNK; }
+static inline size_t gsr_sort_nsuper(size_t n) { return (gsr_sort_nchunks(n) + GSR_SORT_CHUNK - 1) / GSR_SORT_CHUNK; }
 #define GSR_SORT_MAX_PASSES 4
 
-// table memory: [chunk sums of up to 4 passes: 4 x nchunks x RADIX u32, zero before the first pass] [nblocks x RADIX u32]
-size_t gsr_radix_clear_words(size_t n) { return (size_t)GSR_SORT_MAX_PASSES * GSR_SORT_RADIX * gsr_sort_nchunks(n); }
+// table memory: [chunk + super-chunk sums of up to 4 passes: 4 x (nchunks + nsuper) x RADIX u32, zero before the first pass]
+// [nblocks x RADIX u32]
+size_t gsr_radix_clear_words(size_t n) { return (size_t)GSR_SORT_MAX_PASSES * GSR_SORT_RADIX * (gsr_sort_nchunks(n) + gsr_sort_nsuper(n)); }
 
 size_t gsr_radix_table_bytes(size_t n)
 {
@@ -294,7 +318,7 @@ void gsr_radix_sort_passes(uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v
 		if (p >= pass_first) {
 			uint32_t *ki = (p % 2 == 0) ? k0 : k1, *vi = (p % 2 == 0) ? v0 : v1;
 			uint32_t *ko = (p % 2 == 0) ? k1 : k0, *vo = (p % 2 == 0) ? v1 : v0;
-			uint32_t* cs = chunk_base + (size_t)p * GSR_SORT_RADIX * nchunks;
+			uint32_t* cs = chunk_base + (size_t)p * GSR_SORT_RADIX * (nchunks + (int)gsr_sort_nsuper(n));
 			if (items == GSR_SORT_ITEMS_SMALL) gsr_radix_pass<GSR_SORT_ITEMS_SMALL>(ki, vi, ko, vo, n, shift, bits, table, cs, nchunks, bias, s);
 			else gsr_radix_pass<GSR_SORT_ITEMS_LARGE>(ki, vi, ko, vo, n, shift, bits, table, cs, nchunks, bias, s);
 		}
