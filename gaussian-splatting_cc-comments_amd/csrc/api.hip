@@ -158,7 +158,7 @@ extern "C" int gsr_geometry_layout_of(int P, gsr_geometry_layout* o)
 	o->clamped = off;        off = gsr_align_up(off + n);
 	o->sh_ddir = off;        off = gsr_align_up(off + n * 36);
 	o->status = off;         off = gsr_align_up(off + GSR_STATUS_WORDS * 4);
-	o->scan_temp = off;      off = gsr_align_up(off + 2 * gsr_align_up(nb * 4));
+	o->scan_temp = off;      off = gsr_align_up(off + gsr_align_up(nb * 4));
 	o->sort_table = off;     off = gsr_align_up(off + gsr_radix_table_bytes(n));
 	o->total = off;
 	return GSR_OK;
@@ -219,7 +219,6 @@ GsrGeometry gsr_geometry_view(void* blob, int P)
 {
 	gsr_geometry_layout l;
 	gsr_geometry_layout_of(P, &l);
-	const size_t nb = ((size_t)P + GSR_PREPROCESS_BLOCK - 1) / GSR_PREPROCESS_BLOCK;
 	char* b = (char*)blob;
 	GsrGeometry g;
 	g.splat = (GsrSplat*)(b + l.splat);
@@ -233,8 +232,7 @@ GsrGeometry gsr_geometry_view(void* blob, int P)
 	g.clamped = (uint8_t*)(b + l.clamped);
 	g.sh_ddir = (float*)(b + l.sh_ddir);
 	g.status = (uint32_t*)(b + l.status);
-	g.block_sums = (uint32_t*)(b + l.scan_temp);
-	g.sorted_block_sums = (uint32_t*)(b + l.scan_temp + gsr_align_up(nb * 4));
+	g.sorted_block_sums = (uint32_t*)(b + l.scan_temp);
 	g.sort_table = (void*)(b + l.sort_table);
 	return g;
 }

@@ -42,27 +42,6 @@ __device__ __forceinline__ uint32_t gsr_block_incl_scan(uint32_t v, uint32_t* to
 	return incl + base;
 }
 
-// block_sums (per 256-Gaussian workgroup) -> exclusive prefix in place; grand total -> *total_out
-__global__ void __launch_bounds__(1024) gsr_scan_block_sums_kernel(uint32_t* block_sums, int nb, uint32_t* total_out)
-{
-	__shared__ uint32_t lds[1024 / 64];
-	uint32_t carry = 0;
-	for (int base = 0; base < nb; base += 1024) {
-		const int i = base + threadIdx.x;
-		uint32_t v = (i < nb) ? block_sums[i] : 0u;
-		uint32_t total;
-		uint32_t incl = gsr_block_incl_scan<1024>(v, &total, lds);
-		if (i < nb) block_sums[i] = carry + incl - v;
-		carry += total;
-	}
-	if (threadIdx.x == 0 && total_out) *total_out = carry;
-}
-
-void gsr_launch_scan_block_sums(uint32_t* block_sums, int nb, uint32_t* total_out, hipStream_t s)
-{
-	hipLaunchKernelGGL(gsr_scan_block_sums_kernel, dim3(1), dim3(1024), 0, s, block_sums, nb, total_out);
-}
-
 // per-workgroup sums of tiles_touched taken in depth order (perm = Gaussian ids sorted by depth)
 __global__ void __launch_bounds__(GSR_PREPROCESS_BLOCK) gsr_sorted_block_sums_kernel(const uint32_t* __restrict__ perm,
                                                                                     const uint32_t* __restrict__ tiles_touched,

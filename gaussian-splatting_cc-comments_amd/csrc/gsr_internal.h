@@ -37,8 +37,7 @@ struct GsrGeometry {
 	float* sh_ddir;            // [9][P] d(colour channel c)/d(unit view direction) of the visible Gaussians (plane 3c + {x,y,z})
 	uint32_t* status;             // GSR_STATUS_* words
 
-	uint32_t* block_sums;         // (unused since the instance count moved into the status words)
-	uint32_t* sorted_block_sums;  // per-workgroup tile counts in depth order -> exclusive offsets
+	uint32_t* sorted_block_sums;  // per-workgroup tile counts in depth order (the key emission takes their prefix sums itself)
 	void* sort_table;             // radix histogram table for the P-sized depth sort
 };
 
@@ -106,7 +105,6 @@ void gsr_launch_preprocess(const GsrPreprocessArgs& a, hipStream_t s);
 void gsr_launch_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8_t* present, hipStream_t s);
 
 // binning.hip
-void gsr_launch_scan_block_sums(uint32_t* block_sums, int nb, uint32_t* total_out, hipStream_t s);
 void gsr_launch_sorted_block_sums(GsrGeometry g, int P, int result_in_alt, hipStream_t s);
 void gsr_launch_duplicate_keys(GsrGeometry g, int P, int W, uint32_t* keys, uint32_t* vals, uint32_t* clear, size_t clear_words, hipStream_t s);
 void gsr_launch_tile_ranges(const uint32_t* tile_keys, int64_t R, uint2* ranges, int ntiles, uint32_t* valid, hipStream_t s);

@@ -68,7 +68,7 @@ typedef struct {
 	                          that the backward does not read the SH rows again (backward.cu:98-132) */
 	size_t status;         /* u32 device status words (0: prefiltered trap; 2: depth order in the _alt pair; 4..67: partial instance
 	                          counts; 68..131 / 132..195: partial maxima of ~depth key / depth key of the visible Gaussians) */
-	size_t scan_temp;      /* per-workgroup tile counts: original order, then depth order */
+	size_t scan_temp;      /* per-workgroup tile counts in depth order */
 	size_t sort_table;     /* radix histogram table of the depth sort */
 	size_t total;
 } gsr_geometry_layout;

@@ -207,3 +207,64 @@ def test_bench_gpus_2_on_one_gpu_over_gloo():
     assert d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["views_per_step"] == 2
     assert d["alt_exchange"]["mode"] == "allreduce" and d["alt_exchange"]["value"] > 0
     assert d["data"] == "synthetic" and d["kernels"]["render_backward"]["ms"] > 0
+
+
+def _vp_worker(rank, world, port, sh_mode, out_dir):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import view_parallel
+        from diff_gaussian_rasterization import GaussianRasterizer
+        dev = torch.device("cuda:0")
+        P = 5003
+        scene = gsr_scene.make_scene(P, -3.0, sh_degree=3, seed=91)
+        names = ("means3D", "shs", "opacities", "scales", "rotations")
+
+        def view(r):
+            cam = gsr_scene.ring_camera(208, 120, r, 8)
+            dpix = torch.randn(3, 120, 208, generator=torch.Generator().manual_seed(40 + r)).to(dev)
+            return util.hip_settings(scene, cam, 3, dev), dpix
+
+        ex = view_parallel.GradientExchange(P, 16, dev, sh_mode=sh_mode, parts=2)
+        st, dpix = view(rank)
+        q = {k: getattr(scene, k).to(dev).clone().requires_grad_(True) for k in names}
+        m2 = torch.zeros_like(q["means3D"], requires_grad=True)
+        color, radii = view_parallel.rasterize_view_parallel(q["means3D"], m2, q["shs"], q["opacities"], q["scales"], q["rotations"], st, ex)
+        color.backward(dpix)
+        torch.cuda.synchronize()
+        # what the sum over the two views must be: both views rendered here with the plain rasterizer
+        want = {k: 0 for k in names}
+        for r in range(world):
+            st_r, dpix_r = view(r)
+            p = {k: getattr(scene, k).to(dev).clone().requires_grad_(True) for k in names}
+            n2 = torch.zeros_like(p["means3D"], requires_grad=True)
+            c, _ = GaussianRasterizer(st_r)(means2D=n2, **p)
+            c.backward(dpix_r)
+            for k in names:
+                want[k] = want[k] + p[k].grad
+            if r == rank:
+                assert torch.equal(c, color) and torch.equal(n2.grad, m2.grad)   # this rank's own image and screen-space gradient
+        for k in names:
+            err = float((q[k].grad - want[k]).abs().max()) / max(float(want[k].abs().max()), 1e-30)
+            assert err <= 1e-6, (k, err)   # fp32 sum of two views in either order
+        open(os.path.join(out_dir, f"ok{rank}"), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("sh_mode", ["compact", "allreduce"])
+def test_view_parallel_two_ranks_sum_the_gradients_of_two_views(sh_mode, tmp_path):
+    """Two ranks (sharing the box's one GPU, collectives over gloo) each render their own view through
+    view_parallel.rasterize_view_parallel; every parameter gradient must equal the sum of the two views' gradients from
+    the plain rasterizer, and the image / screen-space gradient of a rank its own view's."""
+    _need_gpu()
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_vp_worker, args=(2, port, sh_mode, str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "ok0").exists() and (tmp_path / "ok1").exists()
