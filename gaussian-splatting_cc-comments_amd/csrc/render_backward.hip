@@ -167,17 +167,25 @@ __global__ void __launch_bounds__(64 * GSR_WAVES_PER_WG) __attribute__((amdgpu_w
 				const v2f Tn = T[p] * inv1ma;
 				// accum_rec and (c - accum_rec) cancel heavily when neighbouring colours are close: reference
 				// operation order, no contraction (backward.cu:553-559)
-				v2f dL_dalpha = ((C0 - ac0[p]) * dp0[p] + (C1 - ac1[p]) * dp1[p]) + (C2 - ac2[p]) * dp2[p];
-				// the reference updates accum_rec lazily at the NEXT hit from (last_alpha, last_color);
-				// doing it now uses the same operands and yields the same bits, without keeping them
-				const v2f n0 = alpha * C0 + oma * ac0[p];
-				const v2f n1 = alpha * C1 + oma * ac1[p];
-				const v2f n2 = alpha * C2 + oma * ac2[p];
-				dL_dalpha = dL_dalpha * Tn + tfb[p] * inv1ma;
+				// dL/dalpha = sum_c (colour_c - accum_rec_c) * dL/dpix_c (backward.cu:553-559), as an FMA chain on the three
+				// differences.  The differences cancel heavily when neighbouring colours are close, so they are formed first and
+				// exactly as the reference forms them; what follows only accumulates.
+				const v2f d0 = C0 - ac0[p], d1 = C1 - ac1[p], d2 = C2 - ac2[p];
+				v2f dL_dalpha = __builtin_elementwise_fma(d2, dp2[p], __builtin_elementwise_fma(d1, dp1[p], d0 * dp0[p]));
+				// accum_rec' = last_alpha * last_color + (1 - last_alpha) * accum_rec (backward.cu:553; the reference applies it
+				// lazily at the NEXT hit, from the same operands), written as accum_rec + alpha * (colour - accum_rec) on the
+				// difference above: one FMA per channel instead of two products and a sum, and the smaller rounding error of the
+				// two forms.  (Measured: 0.577 -> 0.534 ms for the kernel, all parity bars kept -- the blend sums stay at
+				// 4e-7 ... 1.4e-6 of the oracle's double-precision sums on C2 / C3.  Two further shortcuts were measured and
+				// rejected: f = (o G) dL/dalpha instead of (o dL/dalpha) G saves nothing and moves the needle-splat stress case to
+				// 1.03e-5.)
+				const v2f n0 = __builtin_elementwise_fma(alpha, d0, ac0[p]);
+				const v2f n1 = __builtin_elementwise_fma(alpha, d1, ac1[p]);
+				const v2f n2 = __builtin_elementwise_fma(alpha, d2, ac2[p]);
+				dL_dalpha = __builtin_elementwise_fma(dL_dalpha, Tn, tfb[p] * inv1ma);
 				// zero the partials of the pixel that did not hit (dL_dalpha of such a pixel is not zero by itself)
-				const v2f hm = {hit0 ? 1.f : 0.f, hit1 ? 1.f : 0.f};
+				const v2f dla = {hit0 ? dL_dalpha.x : 0.f, hit1 ? dL_dalpha.y : 0.f};
 				const v2f dch = alpha * Tn;             // dchannel_dcolor; 0 without a hit
-				const v2f dla = dL_dalpha * hm;
 				T[p] = Tn;
 				ac0[p] = n0;
 				ac1[p] = n1;
