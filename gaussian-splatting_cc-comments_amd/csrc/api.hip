@@ -448,14 +448,14 @@ extern "C" int gsr_forward_render(int P, int64_t R, int width, int height, const
 		gsr_launch_tile_ranges(b.tile_keys, R, im.ranges, ntiles, b.tile_keys_alt, s);
 	}
 	if ((rc = gsr_stage_done(s, debug, "tile_ranges"))) return rc;
-	if (R > 0) {
+	if (R > 0) {  // (measured at C3: the forward's own order is worth 33 us of blend time for ~12 us of this kernel and its launch)
 		GsrProfScope p(s, "tile_order");
 		gsr_launch_tile_order(im, ntiles, false, s);
 	}
 	if ((rc = gsr_stage_done(s, debug, "tile_order"))) return rc;
 	{
 		GsrProfScope p(s, "render_forward");
-		gsr_launch_render_forward(width, height, im, b.point_list, g.splat, background, out_color, R > 0, s);
+				gsr_launch_render_forward(width, height, im, b.point_list, g.splat, background, out_color, R > 0, s);
 	}
 	return gsr_stage_done(s, debug, "render_forward");
 }

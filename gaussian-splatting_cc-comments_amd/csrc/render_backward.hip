@@ -147,7 +147,10 @@ __global__ void __launch_bounds__(64 * GSR_WAVES_PER_WG) __attribute__((amdgpu_w
 				// power = -0.5f * (a*dx*dx + c*dy*dy) - b*dx*dy in the reference's operation order
 				const v2f dy = Y - pfy[p];
 				const v2f power = -0.5f * (ax2 + (CC * dy) * dy) - bdx * dy;
-				const v2f G = {__expf(power.x), __expf(power.y)};
+				// __expf(x) = v_exp_f32(x * log2(e)) (the forward's form, same constant, same IEEE product): the two products as one
+				// packed multiply
+				const v2f pl = power * 1.44269504088896340736f;
+				const v2f G = {__builtin_amdgcn_exp2f(pl.x), __builtin_amdgcn_exp2f(pl.y)};
 				const v2f og = OP * G;
 				const v2f araw = {fminf(0.99f, og.x), fminf(0.99f, og.y)};
 				const bool c0 = contributor < last_contributor[2 * p], p0 = !(power.x > 0.0f), a0 = !(araw.x < 1.0f / 255.0f);
