@@ -10,8 +10,8 @@
 // per-Gaussian-contiguous emission order).  The per-Gaussian kernel then adds each Gaussian's
 // contiguous run of slots in a fixed order: no atomics, no LDS partials, no workgroup barrier,
 // bitwise reproducible.  Per-pixel arithmetic is that of backward.cu:507-599; G and alpha come
-// from the same instruction sequence as in the forward kernel (gsr_pair_power), so the products
-// the forward formed are the ones undone here.
+// from the same roundings as in the forward kernel (gsr_pair_power; the forward's pre-halved conic terms give the same
+// bits), so the products the forward formed are the ones undone here.
 #include "render_common.h"
 
 #define GSR_BWD_NV 9

@@ -85,6 +85,14 @@ __device__ __forceinline__ float gsr_pair_power(float ax2, float bdx, float c, f
 	return __fsub_rn(__fmul_rn(-0.5f, __fadd_rn(ax2, cy2)), __fmul_rn(bdx, dy));
 }
 
+// The same value from conic terms pre-multiplied by -0.5 (ah = -0.5 a, ch = -0.5 c; axh2 = (ah dx) dx): scaling by a
+// power of two commutes with every rounding above, so the bits are those of gsr_pair_power -- one multiply less per pixel.
+__device__ __forceinline__ float gsr_pair_power_halved(float axh2, float bdx, float ch, float dy)
+{
+	const float cyh2 = __fmul_rn(__fmul_rn(ch, dy), dy);
+	return __fsub_rn(__fadd_rn(axh2, cyh2), __fmul_rn(bdx, dy));
+}
+
 // ---- wave64 butterfly reduction of 8 values (gfx950 v_permlane{32,16}_swap + DPP) ----------------
 // Each fold halves the number of live registers instead of reducing every register over all 64
 // lanes: 8 values cost 18 cross-lane ops instead of 48.  On return every lane of the 8-lane group g

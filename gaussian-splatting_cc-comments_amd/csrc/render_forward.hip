@@ -12,9 +12,10 @@
 // are exactly those that blend into no pixel of the tile, so results are unchanged and
 // n_contrib keeps the instance's position in the FULL range (forward.cu:426,466).
 //
-// The reference's per-thread `done` flag is the running transmittance itself here: Trun = 0 once
-// a pixel has stopped (or lies outside the image), which makes every later T-test fail without a
-// separate predicate; Tout keeps the value to report.
+// The reference's per-thread `done` flag is one wave-uniform lane mask per band here (alive[k], two SGPRs): the
+// comparisons of a band produce lane masks anyway, so updating and testing the flag is scalar arithmetic beside the
+// vector instructions; a pixel's T is only ever advanced by a passing instance, so Tout is both the running and the
+// reported transmittance.
 #include "render_common.h"
 
 __global__ void __launch_bounds__(64 * GSR_WAVES_PER_WG) gsr_render_forward_wave_kernel(
@@ -33,22 +34,25 @@ __global__ void __launch_bounds__(64 * GSR_WAVES_PER_WG) gsr_render_forward_wave
 	const int tx = tile % gx, ty = tile / gx;
 	const int px = tx * GSR_TILE_X + (lane & 15);
 	const int py0 = ty * GSR_TILE_Y + (lane >> 4);
-	const float pfx = (float)px;
+	float pfx = (float)px;
+	asm volatile("" : "+v"(pfx));
 	const float x0f = (float)(tx * GSR_TILE_X), y0f = (float)(ty * GSR_TILE_Y);
 
 	const uint2 range = ranges[tile];
 	const int n = (int)(range.y - range.x);
 	const uint32_t* plist = point_list + range.x;
 
-	float Trun[GSR_PIX_PER_LANE], Tout[GSR_PIX_PER_LANE], C0[GSR_PIX_PER_LANE], C1[GSR_PIX_PER_LANE], C2[GSR_PIX_PER_LANE];
+	float Tout[GSR_PIX_PER_LANE], C0[GSR_PIX_PER_LANE], C1[GSR_PIX_PER_LANE], C2[GSR_PIX_PER_LANE];
 	float pfy[GSR_PIX_PER_LANE];
 	uint32_t last[GSR_PIX_PER_LANE];
+	unsigned long long alive[GSR_PIX_PER_LANE];  // lanes whose pixel of band k still blends: wave-uniform, lives in SGPRs
 #pragma unroll
 	for (int k = 0; k < GSR_PIX_PER_LANE; k++) {
 		const int py = py0 + 4 * k;
 		pfy[k] = (float)py;
+		asm volatile("" : "+v"(pfy[k]));  // keep it in its register: the compiler would redo the conversion per instance
 		Tout[k] = 1.0f;
-		Trun[k] = (px < W && py < H) ? 1.0f : 0.0f;
+		alive[k] = __builtin_amdgcn_ballot_w64(px < W && py < H);
 		C0[k] = C1[k] = C2[k] = 0.f;
 		last[k] = 0u;
 	}
@@ -62,15 +66,15 @@ __global__ void __launch_bounds__(64 * GSR_WAVES_PER_WG) gsr_render_forward_wave
 	uint32_t id_next = (64 + lane < n) ? plist[64 + lane] : 0u;
 
 	for (int base = 0; base < n; base += 64) {
-		if (__builtin_amdgcn_ballot_w64(fmaxf(fmaxf(Trun[0], Trun[1]), fmaxf(Trun[2], Trun[3])) > 0.f) == 0ull) break;
+		if ((alive[0] | alive[1] | alive[2] | alive[3]) == 0ull) break;
 		const uint32_t bands = (base + lane < n) ? (cull ? gsr_tile_band_mask(ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, x0f, y0f) : 0xFu) : 0u;
 		const bool keep = bands != 0u;
 		const unsigned long long mask = __builtin_amdgcn_ballot_w64(keep);
 		const int cnt = __popcll(mask);
 		if (keep) {
 			const int pos = gsr_mbcnt(mask);
-			rec[0][pos] = ra;
-			rec[1][pos] = rb;
+			rec[0][pos] = make_float4(ra.x, ra.y, -0.5f * ra.z, ra.w);  // conic a, c pre-multiplied by -0.5 (exact)
+			rec[1][pos] = make_float4(-0.5f * rb.x, rb.y, rb.z, rb.w);
 			rec[2][pos] = make_float4(rc.x, __uint_as_float((uint32_t)(base + lane + 1)), __uint_as_float(bands), 0.f);
 		}
 		if (base + 64 + lane < n) {
@@ -81,8 +85,8 @@ __global__ void __launch_bounds__(64 * GSR_WAVES_PER_WG) gsr_render_forward_wave
 		__builtin_amdgcn_wave_barrier();
 
 		for (int j = 0; j < cnt; j++) {
-			const float4 A = rec[0][j];   // x, y, conic a, conic b
-			const float4 B = rec[1][j];   // conic c, opacity, r, g
+			const float4 A = rec[0][j];   // x, y, -0.5 conic a, conic b
+			const float4 B = rec[1][j];   // -0.5 conic c, opacity, r, g
 			const float4 Cc = rec[2][j];  // b, contributor, band mask
 			const uint32_t contributor = __float_as_uint(Cc.y);
 			const uint32_t bands = __builtin_amdgcn_readfirstlane(__float_as_uint(Cc.z));  // wave-uniform
@@ -91,24 +95,26 @@ __global__ void __launch_bounds__(64 * GSR_WAVES_PER_WG) gsr_render_forward_wave
 #pragma unroll
 			for (int k = 0; k < GSR_PIX_PER_LANE; k++) {
 				if (!(bands & (1u << k))) continue;  // this 16x4 band cannot be reached: scalar branch
-				if (__builtin_amdgcn_ballot_w64(Trun[k] > 0.f) == 0ull) continue;  // all 64 pixels of the band are done
+				if (alive[k] == 0ull) continue;  // all 64 pixels of the band are done
 				const float dy = A.y - pfy[k];
-				const float power = gsr_pair_power(ax2, bdx, B.x, dy);
+				const float power = gsr_pair_power_halved(ax2, bdx, B.x, dy);
 				const float alpha = fminf(0.99f, B.y * __expf(power));
 				// (1 - alpha) is rounded BEFORE the product, as in forward.cu:449: the backward pass divides
 				// by that rounded value, so contracting this into fma(-T, alpha, T) would break the pairing
-				const float test_T = __fmul_rn(Trun[k], __fsub_rn(1.0f, alpha));
-				const bool live = !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
-				const bool pass = live && !(test_T < 0.0001f);  // Trun == 0 (done) can never pass
-				const float w = pass ? alpha * Trun[k] : 0.0f;
+				const float test_T = __fmul_rn(Tout[k], __fsub_rn(1.0f, alpha));
+				// the three comparisons are SGPR lane masks; what follows them is scalar arithmetic
+				const unsigned long long live = __builtin_amdgcn_ballot_w64(!(power > 0.0f)) & __builtin_amdgcn_ballot_w64(!(alpha < 1.0f / 255.0f));
+				const unsigned long long passm = live & alive[k] & __builtin_amdgcn_ballot_w64(!(test_T < 0.0001f));
+				alive[k] = (alive[k] & ~live) | passm;  // a live instance either passes or ends the pixel
+				const bool pass = __builtin_amdgcn_inverse_ballot_w64(passm);
+				const float w = pass ? alpha * Tout[k] : 0.0f;
 				C0[k] = __builtin_fmaf(B.z, w, C0[k]);
 				C1[k] = __builtin_fmaf(B.w, w, C1[k]);
 				C2[k] = __builtin_fmaf(Cc.x, w, C2[k]);
 				Tout[k] = pass ? test_T : Tout[k];
-				Trun[k] = live ? (pass ? test_T : 0.0f) : Trun[k];
 				last[k] = pass ? contributor : last[k];
 			}
-			if (__builtin_amdgcn_ballot_w64(fmaxf(fmaxf(Trun[0], Trun[1]), fmaxf(Trun[2], Trun[3])) > 0.f) == 0ull) break;
+			if ((alive[0] | alive[1] | alive[2] | alive[3]) == 0ull) break;
 		}
 		__builtin_amdgcn_wave_barrier();
 	}
