@@ -17,6 +17,8 @@
 #define GSR_BWD_NV 9
 typedef float v2f __attribute__((ext_vector_type(2)));
 
+GSR_TILE_CLOCK_BUFFER(gsr_backward_tile_clock, gsr_debug_tile_clock_backward)
+
 __global__ void __launch_bounds__(64 * GSR_WAVES_PER_WG) __attribute__((amdgpu_waves_per_eu(4, 4))) gsr_render_backward_wave_kernel(
 	int W, int H, int gx, int ntiles, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
 	const GsrSplat* __restrict__ splat, const uint32_t* __restrict__ slot_base, const float* __restrict__ bg,
@@ -32,6 +34,7 @@ __global__ void __launch_bounds__(64 * GSR_WAVES_PER_WG) __attribute__((amdgpu_w
 	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 	const int slot_id = blockIdx.x * GSR_WAVES_PER_WG + wave;
 	if (slot_id >= ntiles) return;  // wave-uniform; no barriers below
+	GSR_TILE_CLOCK_START();
 	// workgroups are dispatched in index order: tile_order lists the tiles by descending work, so the long tiles
 	// start first and the short ones fill the end of the launch (binning.hip gsr_tile_order_kernel)
 	const int tile = (int)tile_order[slot_id];
@@ -231,6 +234,7 @@ __global__ void __launch_bounds__(64 * GSR_WAVES_PER_WG) __attribute__((amdgpu_w
 		}
 		__builtin_amdgcn_wave_barrier();
 	}
+	GSR_TILE_CLOCK_STOP(gsr_backward_tile_clock, tile, lane);
 }
 
 void gsr_launch_render_backward(int W, int H, GsrImage img, const uint32_t* point_list, const GsrSplat* splat,

@@ -20,6 +20,31 @@ static inline int gsr_culling_enabled()
 #define GSR_WAVES_PER_WG 1
 #define GSR_PIX_PER_LANE 4
 
+// Diagnostic build only (-DGSR_TILE_CLOCK, `make tile_clock`; tools/tile_clock.py): each blend kernel gets a device
+// pointer and every wave records when (100 MHz s_memrealtime) and where (HW_ID, XCC_ID) it ran, four words per tile.
+// The product library has none of it.
+#ifdef GSR_TILE_CLOCK
+#include <hip/hip_runtime.h>
+#define GSR_TILE_CLOCK_BUFFER(sym, setter)                                                           \
+	__device__ unsigned long long* sym = nullptr;                                                    \
+	extern "C" int setter(unsigned long long* buf) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(sym), &buf, sizeof(buf)); }
+#define GSR_TILE_CLOCK_START() const unsigned long long gsr_tc0 = __builtin_amdgcn_s_memrealtime()
+#define GSR_TILE_CLOCK_STOP(sym, tile, lane)                                                         \
+	do {                                                                                             \
+		unsigned long long* gsr_tc = sym;                                                            \
+		if (gsr_tc && (lane) == 0) {                                                                 \
+			gsr_tc[4 * (size_t)(tile)] = gsr_tc0;                                                    \
+			gsr_tc[4 * (size_t)(tile) + 1] = __builtin_amdgcn_s_memrealtime();                       \
+			gsr_tc[4 * (size_t)(tile) + 2] = __builtin_amdgcn_s_getreg((31 << 11) | 4);  /* HW_REG_HW_ID */  \
+			gsr_tc[4 * (size_t)(tile) + 3] = __builtin_amdgcn_s_getreg((31 << 11) | 20); /* HW_REG_XCC_ID */ \
+		}                                                                                            \
+	} while (0)
+#else
+#define GSR_TILE_CLOCK_BUFFER(sym, setter)
+#define GSR_TILE_CLOCK_START()
+#define GSR_TILE_CLOCK_STOP(sym, tile, lane)
+#endif
+
 // Conservative, exact-result-preserving culling.  alpha = o*exp(-q/2) with
 // q = a dx^2 + 2 b dx dy + c dy^2 can reach 1/255 inside a pixel rectangle only if the minimum of
 // q over the rectangle is <= 2 ln(255 o).  The minimum of the convex quadratic over a rectangle is

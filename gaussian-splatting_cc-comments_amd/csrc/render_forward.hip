@@ -18,6 +18,8 @@
 // reported transmittance.
 #include "render_common.h"
 
+GSR_TILE_CLOCK_BUFFER(gsr_forward_tile_clock, gsr_debug_tile_clock_forward)
+
 __global__ void __launch_bounds__(64 * GSR_WAVES_PER_WG) gsr_render_forward_wave_kernel(
 	int W, int H, int gx, int ntiles, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
 	const GsrSplat* __restrict__ splat, const float* __restrict__ bg, float* __restrict__ final_T,
@@ -28,6 +30,7 @@ __global__ void __launch_bounds__(64 * GSR_WAVES_PER_WG) gsr_render_forward_wave
 	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 	const int slot_id = blockIdx.x * GSR_WAVES_PER_WG + wave;
 	if (slot_id >= ntiles) return;  // wave-uniform; no barriers below
+	GSR_TILE_CLOCK_START();
 	const int tile = tile_order ? (int)tile_order[slot_id] : slot_id;  // longest ranges first (binning.hip gsr_tile_order_kernel)
 	float4(*rec)[64] = s_rec[wave];
 
@@ -138,6 +141,7 @@ __global__ void __launch_bounds__(64 * GSR_WAVES_PER_WG) gsr_render_forward_wave
 #pragma unroll
 	for (int off = 32; off > 0; off >>= 1) m = max(m, (uint32_t)__shfl_down(m, off, 64));
 	if (lane == 0) tile_max_contrib[tile] = m;
+	GSR_TILE_CLOCK_STOP(gsr_forward_tile_clock, tile, lane);
 }
 
 void gsr_launch_render_forward(int W, int H, GsrImage img, const uint32_t* point_list, const GsrSplat* splat,
