@@ -203,7 +203,7 @@ __global__ void __launch_bounds__(256) gsr_tile_ranges_kernel(const uint32_t* __
 // work / 16 (1024 bins, saturating) by ONE workgroup; the order inside a bin is arbitrary (it only affects
 // scheduling: every tile's result is independent of when it runs).
 #define GSR_ORDER_BINS 1024
-#define GSR_ORDER_PER_THREAD 8
+#define GSR_ORDER_PER_THREAD 9  // 9 216 tiles per pass: 1920x1080 (8 160) and 1980x1080 (8 432) in one
 // work estimate of a tile: instances the backward will stage (tile_max_contrib given) or the length of its range (the
 // forward's upper bound, before anything is known about where its pixels saturate)
 __device__ __forceinline__ uint32_t gsr_tile_work_bin(const uint2* __restrict__ ranges, const uint32_t* __restrict__ tile_max_contrib, uint32_t t)
@@ -220,10 +220,20 @@ __global__ void __launch_bounds__(1024) gsr_tile_order_kernel(const uint2* __res
 	__shared__ uint32_t bin[GSR_ORDER_BINS];
 	__shared__ uint32_t wsum[1024 / 64];
 	bin[threadIdx.x] = 0;
+	// The kernel is one workgroup of dependent round trips: every pass reads GSR_ORDER_PER_THREAD tiles per thread with all
+	// loads issued before the first use, and the bins of the first 1024 * GSR_ORDER_PER_THREAD tiles (all of them up to
+	// 1080p) stay in registers between the counting and the placing pass.
+	uint32_t b0[GSR_ORDER_PER_THREAD];
+#pragma unroll
+	for (int j = 0; j < GSR_ORDER_PER_THREAD; j++) {
+		const uint32_t t = j * 1024 + threadIdx.x;
+		b0[j] = t < ntiles ? gsr_tile_work_bin(ranges, tile_max_contrib, t) : 0xffffffffu;
+	}
 	__syncthreads();
-	// both passes read GSR_ORDER_PER_THREAD tiles per thread with all loads issued before the first use: the kernel is
-	// one workgroup of dependent round trips otherwise (11 us at 8 432 tiles; 4 us this way)
-	for (uint32_t base = 0; base < ntiles; base += 1024 * GSR_ORDER_PER_THREAD) {
+#pragma unroll
+	for (int j = 0; j < GSR_ORDER_PER_THREAD; j++)
+		if (b0[j] != 0xffffffffu) atomicAdd(&bin[b0[j]], 1u);
+	for (uint32_t base = 1024 * GSR_ORDER_PER_THREAD; base < ntiles; base += 1024 * GSR_ORDER_PER_THREAD) {
 		uint32_t b[GSR_ORDER_PER_THREAD];
 #pragma unroll
 		for (int j = 0; j < GSR_ORDER_PER_THREAD; j++) {
@@ -240,7 +250,10 @@ __global__ void __launch_bounds__(1024) gsr_tile_order_kernel(const uint2* __res
 	const uint32_t incl = gsr_block_incl_scan<1024>(c, &total, wsum);
 	bin[threadIdx.x] = incl - c;  // first position of the bin
 	__syncthreads();
-	for (uint32_t base = 0; base < ntiles; base += 1024 * GSR_ORDER_PER_THREAD) {
+#pragma unroll
+	for (int j = 0; j < GSR_ORDER_PER_THREAD; j++)
+		if (b0[j] != 0xffffffffu) order[atomicAdd(&bin[b0[j]], 1u)] = j * 1024 + threadIdx.x;
+	for (uint32_t base = 1024 * GSR_ORDER_PER_THREAD; base < ntiles; base += 1024 * GSR_ORDER_PER_THREAD) {
 		uint32_t b[GSR_ORDER_PER_THREAD];
 #pragma unroll
 		for (int j = 0; j < GSR_ORDER_PER_THREAD; j++) {

@@ -125,6 +125,7 @@ __device__ __forceinline__ void gsr_cov3d_backward(const float* scale, float mod
 // time no longer follows its single most-loaded lane.  The order is fixed: bitwise reproducible.
 #define GSR_SLOT_COOP 18   // swept on MI355X at C3: 12 / 18 / 24 / 36 -> 0.172 / 0.164 / 0.166 / 0.171 ms
 #define GSR_NACC 9
+#define GSR_VALID_WORDS ((GSR_SLOT_COOP + 3 + 3) / 4)  // aligned dwords that cover GSR_SLOT_COOP bytes at any byte offset
 
 __device__ __forceinline__ void gsr_add_slot(const GsrGradSlot* __restrict__ slots, const uint8_t* __restrict__ valid,
                                              uint32_t s, float* acc)
@@ -191,39 +192,51 @@ __global__ void __launch_bounds__(GSR_GB_THREADS) gsr_gaussian_backward_kernel(G
 	const bool visible = in_range && (a.radii ? radius > 0 : tiles > 0);
 	if (!visible) tiles = 0;
 
-	// ---- (C) validity bytes of all the slots a lane sums by itself ----
+	// ---- (C) validity bytes of all the slots a lane sums by itself: its <= GSR_SLOT_COOP bytes sit in at most
+	//      GSR_VALID_WORDS consecutive aligned dwords (every lane's loads go to lines of its own, so the cost of this step
+	//      is its number of load instructions: 6 instead of 18).  Bytes are 0 or 1 (render_backward.hip / tile_ranges).
 	uint32_t vmask = 0;
-	if (tiles <= GSR_SLOT_COOP) {
-		uint8_t vb[GSR_SLOT_COOP];
+	if (tiles > 0 && tiles <= GSR_SLOT_COOP) {
+		const uint32_t lead = base & 3u;
+		const uint32_t* vp = reinterpret_cast<const uint32_t*>(a.slot_valid + (base - lead));  // slot_valid itself is 128-byte aligned
+		uint32_t w[GSR_VALID_WORDS];
 #pragma unroll
-		for (int j = 0; j < GSR_SLOT_COOP; j++) vb[j] = ((uint32_t)j < tiles) ? a.slot_valid[base + j] : (uint8_t)0;
+		for (int i = 0; i < GSR_VALID_WORDS; i++) w[i] = (4u * i < lead + tiles) ? vp[i] : 0u;  // the words behind the run belong to the buffer (4 R bytes, R used)
+		unsigned long long bits = 0ull;
 #pragma unroll
-		for (int j = 0; j < GSR_SLOT_COOP; j++) vmask |= vb[j] ? (1u << j) : 0u;
+		for (int i = 0; i < GSR_VALID_WORDS; i++) {
+			const uint32_t b4 = (w[i] & 1u) | ((w[i] >> 7) & 2u) | ((w[i] >> 14) & 4u) | ((w[i] >> 21) & 8u);
+			bits |= (unsigned long long)b4 << (4 * i);
+		}
+		vmask = (uint32_t)(bits >> lead) & ((1u << tiles) - 1u);
 	}
-	// ---- (E) fixed-order sum of this Gaussian's (Gaussian,tile) slots ----
+	// ---- (E) fixed-order sum of this Gaussian's (Gaussian,tile) slots: its VALID slots in ascending order, six per round;
+	//      the records of a round are all requested before the first add, and only by the lanes that have one (a lane's
+	//      record is a line of its own here too: masked-off lanes cost nothing)
 	float acc[GSR_NACC];
 #pragma unroll
 	for (int i = 0; i < GSR_NACC; i++) acc[i] = 0.f;
-	if (vmask) {
-		// six slots per round: their records are all requested before the first add; the addition order is the slot order
+	uint32_t rem = vmask;
+	while (rem) {
+		float4 s0[6], s1[6];
+		float s2[6];
+		bool ok[6];
 #pragma unroll
-		for (int k = 0; k < GSR_SLOT_COOP; k += 6) {
-			if (!(vmask >> k)) break;
-			float4 s0[6], s1[6];
-			float s2[6];
-#pragma unroll
-			for (int j = 0; j < 6; j++) {
-				const bool ok = (vmask >> (k + j)) & 1u;
-				const float4* sl = reinterpret_cast<const float4*>(a.slots + (ok ? base + k + j : base));
+		for (int j = 0; j < 6; j++) {
+			ok[j] = rem != 0u;
+			const uint32_t k = (uint32_t)__builtin_ctz(rem | 0x80000000u);
+			rem &= rem - 1u;
+			if (ok[j]) {
+				const float4* sl = reinterpret_cast<const float4*>(a.slots + (base + k));
 				s0[j] = sl[0]; s1[j] = sl[1]; s2[j] = sl[2].x;
 			}
-#pragma unroll
-			for (int j = 0; j < 6; j++)
-				if ((vmask >> (k + j)) & 1u) {
-					acc[0] += s0[j].x; acc[1] += s0[j].y; acc[2] += s0[j].z; acc[3] += s0[j].w; acc[4] += s1[j].x;
-					acc[5] += s1[j].y; acc[6] += s1[j].z; acc[7] += s1[j].w; acc[8] += s2[j];
-				}
 		}
+#pragma unroll
+		for (int j = 0; j < 6; j++)
+			if (ok[j]) {
+				acc[0] += s0[j].x; acc[1] += s0[j].y; acc[2] += s0[j].z; acc[3] += s0[j].w; acc[4] += s1[j].x;
+				acc[5] += s1[j].y; acc[6] += s1[j].z; acc[7] += s1[j].w; acc[8] += s2[j];
+			}
 	}
 	unsigned long long big = __builtin_amdgcn_ballot_w64(tiles > GSR_SLOT_COOP);
 	while (big) {  // wave-uniform
