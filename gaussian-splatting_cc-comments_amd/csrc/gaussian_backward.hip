@@ -125,6 +125,9 @@ __device__ __forceinline__ void gsr_cov3d_backward(const float* scale, float mod
 // time no longer follows its single most-loaded lane.  The order is fixed: bitwise reproducible.
 #define GSR_SLOT_COOP 18   // swept on MI355X at C3: 12 / 18 / 24 / 36 -> 0.172 / 0.164 / 0.166 / 0.171 ms
 #define GSR_NACC 9
+#ifndef GSR_SLOT_ROUND
+#define GSR_SLOT_ROUND 6   // slot records requested per round of the per-lane sum
+#endif
 #define GSR_VALID_WORDS ((GSR_SLOT_COOP + 3 + 3) / 4)  // aligned dwords that cover GSR_SLOT_COOP bytes at any byte offset
 
 __device__ __forceinline__ void gsr_add_slot(const GsrGradSlot* __restrict__ slots, const uint8_t* __restrict__ valid,
@@ -218,11 +221,11 @@ __global__ void __launch_bounds__(GSR_GB_THREADS) gsr_gaussian_backward_kernel(G
 	for (int i = 0; i < GSR_NACC; i++) acc[i] = 0.f;
 	uint32_t rem = vmask;
 	while (rem) {
-		float4 s0[6], s1[6];
-		float s2[6];
-		bool ok[6];
+		float4 s0[GSR_SLOT_ROUND], s1[GSR_SLOT_ROUND];
+		float s2[GSR_SLOT_ROUND];
+		bool ok[GSR_SLOT_ROUND];
 #pragma unroll
-		for (int j = 0; j < 6; j++) {
+		for (int j = 0; j < GSR_SLOT_ROUND; j++) {
 			ok[j] = rem != 0u;
 			const uint32_t k = (uint32_t)__builtin_ctz(rem | 0x80000000u);
 			rem &= rem - 1u;
@@ -232,7 +235,7 @@ __global__ void __launch_bounds__(GSR_GB_THREADS) gsr_gaussian_backward_kernel(G
 			}
 		}
 #pragma unroll
-		for (int j = 0; j < 6; j++)
+		for (int j = 0; j < GSR_SLOT_ROUND; j++)
 			if (ok[j]) {
 				acc[0] += s0[j].x; acc[1] += s0[j].y; acc[2] += s0[j].z; acc[3] += s0[j].w; acc[4] += s1[j].x;
 				acc[5] += s1[j].y; acc[6] += s1[j].z; acc[7] += s1[j].w; acc[8] += s2[j];

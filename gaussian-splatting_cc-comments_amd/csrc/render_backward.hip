@@ -114,8 +114,10 @@ __global__ void __launch_bounds__(64 * GSR_WAVES_PER_WG) __attribute__((amdgpu_w
 			const uint32_t rmin = __float_as_uint(rc.z), rwh = __float_as_uint(rc.w);
 			const uint32_t slot = sbase + ((uint32_t)ty - (rmin >> 16)) * (rwh & 0xffffu) + ((uint32_t)tx - (rmin & 0xffffu));
 			rec[0][pos] = make_float4(ra.x, ra.x, ra.y, ra.y);  // mean x, y
-			rec[1][pos] = make_float4(ra.z, ra.z, ra.w, ra.w);  // conic a, b
-			rec[2][pos] = make_float4(rb.x, rb.x, rb.y, rb.y);  // conic c, opacity
+			// conic a and c pre-multiplied by -0.5: a power of two commutes with every rounding of `power`, so its bits are the
+			// forward's (gsr_pair_power_halved) with one packed multiply less per pair; the epilogue undoes it inside an FMA
+			rec[1][pos] = make_float4(-0.5f * ra.z, -0.5f * ra.z, ra.w, ra.w);  // -0.5 conic a, conic b
+			rec[2][pos] = make_float4(-0.5f * rb.x, -0.5f * rb.x, rb.y, rb.y);  // -0.5 conic c, opacity
 			rec[3][pos] = make_float4(rb.z, rb.z, rb.w, rb.w);  // r, g
 			rec[4][pos] = make_float4(rc.x, rc.x, __int_as_float(n - 1 - (base + lane)), __uint_as_float(slot));  // b, position in the full range, slot
 			recb[pos] = bands;
@@ -142,14 +144,14 @@ __global__ void __launch_bounds__(64 * GSR_WAVES_PER_WG) __attribute__((amdgpu_w
 			// once per instance after the reduction.
 			v2f acc[GSR_BWD_NV];
 #pragma unroll
-			for (int i = 0; i < GSR_BWD_NV; i++) acc[i] = v2f{0.f, 0.f};
+			for (int i = 0; i < GSR_BWD_NV; i++) acc[i] = v2f{-0.f, -0.f};  // x + (-0) is x for every x: the first pair's sums need no add
 			unsigned long long any = 0ull;  // lanes with a hit, kept as a scalar mask: the loop's branches test masks, not ballots of bools
 #pragma unroll
 			for (int p = 0; p < 2; p++) {
 				if (!(bands & (3u << (2 * p))) || contributor >= pair_last[p]) continue;  // scalar branch: no band of this pair can be reached
-				// power = -0.5f * (a*dx*dx + c*dy*dy) - b*dx*dy in the reference's operation order
+				// power = -0.5f * (a*dx*dx + c*dy*dy) - b*dx*dy in the reference's operation order (CA, CC carry the -0.5)
 				const v2f dy = Y - pfy[p];
-				const v2f power = -0.5f * (ax2 + (CC * dy) * dy) - bdx * dy;
+				const v2f power = (ax2 + (CC * dy) * dy) - bdx * dy;
 				// __expf(x) = v_exp_f32(x * log2(e)) (the forward's form, same constant, same IEEE product): the two products as one
 				// packed multiply
 				const v2f pl = power * 1.44269504088896340736f;
@@ -221,8 +223,9 @@ __global__ void __launch_bounds__(64 * GSR_WAVES_PER_WG) __attribute__((amdgpu_w
 				const uint32_t slot = __builtin_amdgcn_readfirstlane(__float_as_uint(R4.w));
 				float* out = reinterpret_cast<float*>(slots + slot);
 				// every lane evaluates all three forms and selects by its (loop-invariant) output index: no exec-mask regions
-				const float rx = -ddelx_dx * (CA.x * sx + CB.x * sy);  // dL/dmean2D.x
-				const float ry = -ddely_dy * (CC.x * sy + CB.x * sx);  // dL/dmean2D.y
+				// a sx + b sy with a = -2 CA: fma(-2, CA sx, b sy) rounds once, after two exact scalings -- the bits of the plain sum
+				const float rx = -ddelx_dx * __builtin_fmaf(-2.0f, CA.x * sx, CB.x * sy);  // dL/dmean2D.x
+				const float ry = -ddely_dy * __builtin_fmaf(-2.0f, CC.x * sy, CB.x * sx);  // dL/dmean2D.y
 				const float rk = out_scale * t8;                       // dL/dconic .x .y .w (x -0.5); opacity and colour as they are
 				const float r = out_index == 0 ? rx : (out_index == 1 ? ry : rk);
 				if ((lane & 7) == 0) out[out_index] = r;

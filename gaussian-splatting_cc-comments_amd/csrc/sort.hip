@@ -30,6 +30,9 @@
 #define GSR_SORT_ITEMS_LARGE 16
 #define GSR_SORT_ITEMS_SMALL 4
 #define GSR_SORT_SMALL_N (4u << 20)
+#ifndef GSR_WALK_ROWS
+#define GSR_WALK_ROWS 8    // rows of the offset tables a wave keeps in flight (one uint4 per lane each)
+#endif
 #define GSR_SORT_CHUNK 64   // blocks per chunk, chunks per super-chunk of the three-level offset table
 
 // min / range of the biased keys from the 64 + 64 partial maxima {max(~key)}, {max(key)} (GsrGeometry::status)
@@ -124,7 +127,10 @@ __global__ void __launch_bounds__(GSR_SORT_THREADS) gsr_radix_scatter_kernel(
 	__shared__ uint32_t gofs[GSR_SORT_RADIX];                           // global base of a digit minus its local base
 	__shared__ uint32_t wsum[GSR_SORT_THREADS / 64];
 	constexpr int TILE = GSR_SORT_THREADS * ITEMS;
-	__shared__ uint32_t skey[TILE], sval[TILE];       // the block's elements in digit order
+	__shared__ __attribute__((aligned(16))) uint32_t sstage[2 * TILE];  // the block's elements in digit order; before that, the offset walk's partial sums
+	static_assert(2 * TILE >= 2 * (GSR_SORT_THREADS / 64) * GSR_SORT_RADIX, "the walk's partial sums must fit the staging area");
+	uint32_t* const skey = sstage;
+	uint32_t* const sval = sstage + TILE;
 	__shared__ uint32_t s_bias[2];
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	const uint32_t mask = (1u << nbits) - 1u;
@@ -143,45 +149,94 @@ __global__ void __launch_bounds__(GSR_SORT_THREADS) gsr_radix_scatter_kernel(
 		val[it] = valid ? vals_in[i] : 0u;
 	}
 
-	// global exclusive base of digit d = (sum of totals of smaller digits) + this block's offset in d.  Thread d walks the
-	// chunk sums of its digit (total, and the part in front of this block's chunk) and the counts of the blocks of this
-	// chunk in front of this block: all loads of a group are issued before the first add.
+	// global exclusive base of digit d = (sum of totals of smaller digits) + this block's offset in d.  The rows that
+	// enter it -- [super][digit] (three levels only), [chunk][digit], [block][digit] of this chunk's earlier blocks; <= nsuper
+	// + 63 + 63 of them whatever the size of the sort -- are ONE list, dealt round-robin to the four waves: a lane reads
+	// digits 4l .. 4l+3 of a row (one coalesced kilobyte per wave instruction), GSR_WALK_ROWS rows in flight per wave (32
+	// rows per workgroup and round trip; the per-thread walk below does 16, and restarts for each of the three tables).
+	// The waves' partial sums meet in LDS (in the staging area, which is not in use yet).  Instance-sized sorts only:
+	// tile sort 1.33 -> 1.22 ms at R = 71M (C5), 0.147 -> 0.146 ms at R = 9.2M (C3); 16 rows in flight cost 150 VGPRs and
+	// were slower.
 	uint32_t my_gbase;
 	{
 		uint32_t v = 0, before = 0;
-		const int my_chunk = blockIdx.x / GSR_SORT_CHUNK, my_super = my_chunk / GSR_SORT_CHUNK;
-		const int nsuper = (nchunks + GSR_SORT_CHUNK - 1) / GSR_SORT_CHUNK;
-		// [super][digit], [chunk][digit] and [block][digit] rows: thread d reads word d of every row, so each load instruction
-		// of the workgroup fetches one contiguous kilobyte; 16 loads are in flight per group.  Total of the digit = all
-		// super-chunks; in front of this block = earlier super-chunks + earlier chunks of its super-chunk + earlier blocks of
-		// its chunk: <= nsuper + 63 + 63 rows whatever the size of the sort
-		const uint32_t* super_sums = chunk_sums + (size_t)nchunks * GSR_SORT_RADIX;
-		const bool three_level = nchunks > GSR_SORT_CHUNK;  // uniform
-		if (three_level) {
-			for (int c0 = 0; c0 < nsuper; c0 += 16) {
+		if constexpr (ITEMS == GSR_SORT_ITEMS_LARGE) {
+			const int my_chunk = blockIdx.x / GSR_SORT_CHUNK, my_super = my_chunk / GSR_SORT_CHUNK;
+			const bool three_level = nchunks > GSR_SORT_CHUNK;  // uniform
+			const int nS = three_level ? (nchunks + GSR_SORT_CHUNK - 1) / GSR_SORT_CHUNK : 0;
+			// two levels: every chunk (total, and the part in front); three levels: only the chunks of this super-chunk in front
+			const int c_first = three_level ? my_super * GSR_SORT_CHUNK : 0, c_end = three_level ? my_chunk : nchunks;
+			const int nC = c_end - c_first;
+			const int b0 = my_chunk * GSR_SORT_CHUNK, nB = (int)blockIdx.x - b0;  // blocks of this chunk in front of this one
+			const int Q = nS + nC + nB;
+			const uint32_t* super_sums = chunk_sums + (size_t)nchunks * GSR_SORT_RADIX;
+			uint4 v4 = make_uint4(0u, 0u, 0u, 0u), bf4 = v4;
+			for (int q0 = wave; q0 < Q; q0 += GSR_WALK_ROWS * (GSR_SORT_THREADS / 64)) {
+				uint4 t[GSR_WALK_ROWS];
+#pragma unroll
+				for (int j = 0; j < GSR_WALK_ROWS; j++) {
+					const int q = q0 + j * (GSR_SORT_THREADS / 64);
+					const uint32_t* row = q < nS ? super_sums + (size_t)q * GSR_SORT_RADIX
+					                    : q < nS + nC ? chunk_sums + (size_t)(c_first + q - nS) * GSR_SORT_RADIX
+					                                  : table + (size_t)(b0 + q - nS - nC) * GSR_SORT_RADIX;
+					t[j] = q < Q ? reinterpret_cast<const uint4*>(row)[lane] : make_uint4(0u, 0u, 0u, 0u);
+				}
+#pragma unroll
+				for (int j = 0; j < GSR_WALK_ROWS; j++) {
+					const int q = q0 + j * (GSR_SORT_THREADS / 64);
+					const bool to_total = three_level ? q < nS : (q >= nS && q < nS + nC);
+					const bool to_before = q < nS ? q < my_super : (q < nS + nC ? c_first + q - nS < my_chunk : true);
+					if (to_total) { v4.x += t[j].x; v4.y += t[j].y; v4.z += t[j].z; v4.w += t[j].w; }
+					if (to_before) { bf4.x += t[j].x; bf4.y += t[j].y; bf4.z += t[j].z; bf4.w += t[j].w; }
+				}
+			}
+			uint4* part = reinterpret_cast<uint4*>(sstage);  // [total | before][wave][lane] uint4 = [total | before][wave][digit] words
+			part[wave * 64 + lane] = v4;
+			part[(GSR_SORT_THREADS / 64 + wave) * 64 + lane] = bf4;
+			__syncthreads();
+#pragma unroll
+			for (int w = 0; w < GSR_SORT_THREADS / 64; w++) {
+				v += sstage[w * GSR_SORT_RADIX + threadIdx.x];
+				before += sstage[(GSR_SORT_THREADS / 64 + w) * GSR_SORT_RADIX + threadIdx.x];
+			}
+		} else {
+			// Gaussian-sized sorts (1024-element blocks): a block lives too briefly for the extra barrier of the
+			// cooperative walk to pay (measured: 71 -> 81 us for the three depth passes at P = 1M); thread d walks word d of the
+			// rows itself, 16 loads in flight
+			const int my_chunk = blockIdx.x / GSR_SORT_CHUNK, my_super = my_chunk / GSR_SORT_CHUNK;
+			const int nsuper = (nchunks + GSR_SORT_CHUNK - 1) / GSR_SORT_CHUNK;
+			// [super][digit], [chunk][digit] and [block][digit] rows: thread d reads word d of every row, so each load instruction
+			// of the workgroup fetches one contiguous kilobyte; 16 loads are in flight per group.  Total of the digit = all
+			// super-chunks; in front of this block = earlier super-chunks + earlier chunks of its super-chunk + earlier blocks of
+			// its chunk: <= nsuper + 63 + 63 rows whatever the size of the sort
+			const uint32_t* super_sums = chunk_sums + (size_t)nchunks * GSR_SORT_RADIX;
+			const bool three_level = nchunks > GSR_SORT_CHUNK;  // uniform
+			if (three_level) {
+				for (int c0 = 0; c0 < nsuper; c0 += 16) {
+					uint32_t t[16];
+#pragma unroll
+					for (int j = 0; j < 16; j++) t[j] = (c0 + j < nsuper) ? super_sums[(size_t)(c0 + j) * GSR_SORT_RADIX + threadIdx.x] : 0u;
+#pragma unroll
+					for (int j = 0; j < 16; j++) { v += t[j]; before += (c0 + j < my_super) ? t[j] : 0u; }
+				}
+			}
+			// two levels: every chunk (total and the part in front); three levels: only the chunks of this super-chunk in front
+			const int c_first = three_level ? my_super * GSR_SORT_CHUNK : 0, c_end = three_level ? my_chunk : nchunks;
+			for (int c0 = c_first; c0 < c_end; c0 += 16) {
 				uint32_t t[16];
 #pragma unroll
-				for (int j = 0; j < 16; j++) t[j] = (c0 + j < nsuper) ? super_sums[(size_t)(c0 + j) * GSR_SORT_RADIX + threadIdx.x] : 0u;
+				for (int j = 0; j < 16; j++) t[j] = (c0 + j < c_end) ? chunk_sums[(size_t)(c0 + j) * GSR_SORT_RADIX + threadIdx.x] : 0u;
 #pragma unroll
-				for (int j = 0; j < 16; j++) { v += t[j]; before += (c0 + j < my_super) ? t[j] : 0u; }
+				for (int j = 0; j < 16; j++) { if (!three_level) v += t[j]; before += (c0 + j < my_chunk) ? t[j] : 0u; }
 			}
-		}
-		// two levels: every chunk (total and the part in front); three levels: only the chunks of this super-chunk in front
-		const int c_first = three_level ? my_super * GSR_SORT_CHUNK : 0, c_end = three_level ? my_chunk : nchunks;
-		for (int c0 = c_first; c0 < c_end; c0 += 16) {
-			uint32_t t[16];
+			const int b0 = my_chunk * GSR_SORT_CHUNK, nb = (int)blockIdx.x - b0;  // blocks of this chunk in front of this one
+			for (int j0 = 0; j0 < nb; j0 += 16) {
+				uint32_t t[16];
 #pragma unroll
-			for (int j = 0; j < 16; j++) t[j] = (c0 + j < c_end) ? chunk_sums[(size_t)(c0 + j) * GSR_SORT_RADIX + threadIdx.x] : 0u;
+				for (int j = 0; j < 16; j++) t[j] = (j0 + j < nb) ? table[(size_t)(b0 + j0 + j) * GSR_SORT_RADIX + threadIdx.x] : 0u;
 #pragma unroll
-			for (int j = 0; j < 16; j++) { if (!three_level) v += t[j]; before += (c0 + j < my_chunk) ? t[j] : 0u; }
-		}
-		const int b0 = my_chunk * GSR_SORT_CHUNK, nb = (int)blockIdx.x - b0;  // blocks of this chunk in front of this one
-		for (int j0 = 0; j0 < nb; j0 += 16) {
-			uint32_t t[16];
-#pragma unroll
-			for (int j = 0; j < 16; j++) t[j] = (j0 + j < nb) ? table[(size_t)(b0 + j0 + j) * GSR_SORT_RADIX + threadIdx.x] : 0u;
-#pragma unroll
-			for (int j = 0; j < 16; j++) before += t[j];
+				for (int j = 0; j < 16; j++) before += t[j];
+			}
 		}
 		uint32_t incl = v;
 #pragma unroll
