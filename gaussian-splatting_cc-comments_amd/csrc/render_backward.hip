@@ -184,7 +184,7 @@ __global__ void __launch_bounds__(64 * GSR_WAVES_PER_WG) __attribute__((amdgpu_w
 				// lazily at the NEXT hit, from the same operands), written as accum_rec + alpha * (colour - accum_rec) on the
 				// difference above: one FMA per channel instead of two products and a sum, and the smaller rounding error of the
 				// two forms.  (Measured: 0.577 -> 0.534 ms for the kernel, all parity bars kept -- the blend sums stay at
-				// 4e-7 ... 1.4e-6 of the oracle's double-precision sums on C2 / C3.  Two further shortcuts were measured and
+				// 4e-7 ... 1.4e-6 of the CPU oracle's double-precision sums on C2 / C3.  Two further shortcuts were measured and
 				// rejected: f = (o G) dL/dalpha instead of (o dL/dalpha) G saves nothing and moves the needle-splat stress case to
 				// 1.03e-5.)
 				const v2f n0 = __builtin_elementwise_fma(alpha, d0, ac0[p]);
