@@ -35,6 +35,7 @@ if not os.path.exists(PMC_SUMMARY):
     PMC_SUMMARY = os.path.join(ROOT, "profiles", "r1_pmc_summary.json")
 KERNEL_SYMBOL = {"render_backward": "gsr_render_backward_wave_kernel", "render_forward": "gsr_render_forward_wave_kernel",
                  "gaussian_backward": "gsr_gaussian_backward_kernel", "preprocess": "gsr_preprocess_kernel",
+                 "preprocess_color": "gsr_preprocess_color_kernel",
                  "duplicate_keys": "gsr_duplicate_keys_kernel", "tile_ranges": "gsr_tile_ranges_kernel"}
 
 
@@ -63,7 +64,8 @@ def algorithmic_bytes(P, V, R, Rp, N, T, M):
     """SURVEY.md section 8(d) per-stage algorithmic bytes (deg-3 SH: 4*3*M = 192 B)."""
     sh = 12 * M
     fwd = {
-        "preprocess": (44 * P + sh * V) + (8 * P + 67 * V),
+        "preprocess": 44 * P + (8 * P + 54 * V),       # geometry kernel; with the colour kernel: SURVEY's (44 P + sh V) + (8 P + 67 V)
+        "preprocess_color": sh * V + 13 * V,            # SH rows in, colour + clamp flags out
         "scan": 8 * P,
         "duplicate_keys": 20 * P + 12 * R,
         "sort": 24 * R,

@@ -106,6 +106,16 @@ void gsr_prof_mark_end(hipStream_t s)
 	(void)hipEventRecord(r->ev[r->used - 1].b, s);
 }
 
+// true while a recorder on this stream records EVERY stage (bench.py's per-kernel table): stages that normally
+// overlap on a helper stream then run in line, so that each gets a time of its own
+static bool gsr_prof_records_all(hipStream_t s)
+{
+	if (g_prof_active.load(std::memory_order_relaxed) == 0) return false;
+	std::lock_guard<std::mutex> lk(g_prof_mu);
+	ProfRecorder* r = prof_find(s, false);
+	return r && r->on && !r->only[0];
+}
+
 extern "C" int gsr_profile_begin_only(void* stream, const char* stage)
 {
 	std::lock_guard<std::mutex> lk(g_prof_mu);
@@ -323,21 +333,56 @@ static int gsr_forward_preprocess_impl(int P, int D, int M, int width, int heigh
 	a.g = gsr_geometry_view(geometry, P);
 
 	int rc;
+	int device = 0;
+	if ((rc = gsr_check_hip(hipGetDevice(&device), "hipGetDevice"))) return rc;
+	if (device < 0 || device >= GSR_MAX_DEVICES) return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "device index %d not supported", device);
+	// The SH colours are needed by nothing before the blend: their kernel runs on a helper stream (one per host thread and
+	// device, created on first use) beside the geometry kernel and the depth sort, whose launches are short and leave most
+	// of the chip idle, and is joined before this call's last kernel.  In line instead when every stage is being timed, in
+	// debug mode (a device sync follows every stage) and with GSR_SERIAL=1.
+	static thread_local hipStream_t aux_stream_of[GSR_MAX_DEVICES] = {nullptr};
+	static thread_local hipEvent_t aux_fork_of[GSR_MAX_DEVICES] = {nullptr}, aux_join_of[GSR_MAX_DEVICES] = {nullptr};
+	const bool color = gsr_preprocess_needs_color(a);
+	bool beside = color && !debug && !gsr_prof_records_all(s);
+	if (beside) {
+		const char* e = getenv("GSR_SERIAL");
+		if (e && e[0] == '1') beside = false;
+	}
+	if (beside && !aux_stream_of[device]) {
+		hipStream_t st = nullptr;
+		hipEvent_t f = nullptr, j = nullptr;
+		if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&f, hipEventDisableTiming) == hipSuccess &&
+		    hipEventCreateWithFlags(&j, hipEventDisableTiming) == hipSuccess) {
+			aux_stream_of[device] = st; aux_fork_of[device] = f; aux_join_of[device] = j;
+		} else {
+			(void)hipGetLastError();
+			beside = false;  // no helper stream: the colour kernel runs in line
+		}
+	}
+	if (beside) {
+		// fork: the helper stream starts where the caller's stream stands now (its inputs are ready there)
+		if ((rc = gsr_check_hip(hipEventRecord(aux_fork_of[device], s), "hipEventRecord(fork)"))) return rc;
+		if ((rc = gsr_check_hip(hipStreamWaitEvent(aux_stream_of[device], aux_fork_of[device], 0), "hipStreamWaitEvent(fork)"))) return rc;
+		gsr_launch_preprocess_color(a, aux_stream_of[device]);
+		if ((rc = gsr_check_hip(hipEventRecord(aux_join_of[device], aux_stream_of[device]), "hipEventRecord(join)"))) return rc;
+	}
 	if ((rc = gsr_check_hip(hipMemsetAsync(a.g.status, 0, GSR_STATUS_WORDS * 4, s), "hipMemsetAsync(status)"))) return rc;
 	{
 		GsrProfScope p(s, "preprocess");
 		gsr_launch_preprocess(a, s);
 	}
 	if ((rc = gsr_stage_done(s, debug, "preprocess"))) return rc;
+	if (color && !beside) {
+		GsrProfScope p(s, "preprocess_color");
+		gsr_launch_preprocess_color(a, s);
+	}
+	if ((rc = gsr_stage_done(s, debug, "preprocess_color"))) return rc;
 
 	// read num_rendered back; the per-Gaussian half of the sort is enqueued behind the copy and keeps
 	// the GPU busy while the host waits on the event, allocates the binning buffer and launches stage 2
 	// pinned landing buffer + event, created once per (thread, device) and reused
 	static thread_local uint32_t* status_host_of[GSR_MAX_DEVICES] = {nullptr};
 	static thread_local hipEvent_t event_of[GSR_MAX_DEVICES] = {nullptr};
-	int device = 0;
-	if ((rc = gsr_check_hip(hipGetDevice(&device), "hipGetDevice"))) return rc;
-	if (device < 0 || device >= GSR_MAX_DEVICES) return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "device index %d not supported", device);
 	if (!status_host_of[device]) {
 		if ((rc = gsr_check_hip(hipHostMalloc((void**)&status_host_of[device], GSR_STATUS_WORDS * 4, hipHostMallocDefault), "hipHostMalloc"))) return rc;
 		if ((rc = gsr_check_hip(hipEventCreateWithFlags(&event_of[device], hipEventDisableTiming), "hipEventCreate"))) return rc;
@@ -356,8 +401,10 @@ static int gsr_forward_preprocess_impl(int P, int D, int M, int width, int heigh
 	}
 	if ((rc = gsr_stage_done(s, debug, "depth_sort"))) return rc;
 	if ((rc = gsr_check_hip(hipEventSynchronize(ev), "hipEventSynchronize(num_rendered)"))) return rc;
-	if (status_host[0] & 1u)
+	if (status_host[0] & 1u) {
+		if (beside) (void)hipStreamWaitEvent(s, aux_join_of[device], 0);
 		return gsr_fail(GSR_ERR_PREFILTERED, "Point is filtered although prefiltered is set. This shouldn't happen!");
+	}
 	int64_t total = 0;
 	uint32_t negmin = 0, kmax = 0;
 	for (int k = 0; k < GSR_COUNT_PARTS; k++) {
@@ -369,6 +416,8 @@ static int gsr_forward_preprocess_impl(int P, int D, int M, int width, int heigh
 	const uint32_t kmin = ~negmin;
 	const uint32_t culled_value = kmax >= kmin ? (kmax - kmin) + 1u : 0u;   // largest biased key (what culled Gaussians sort as)
 	const int fourth = (culled_value >> 24) != 0u || (kmax >= kmin && kmax - kmin == 0xFFFFFFFFu);
+	// join: everything the caller enqueues after this call comes after the colour kernel too
+	if (beside && (rc = gsr_check_hip(hipStreamWaitEvent(s, aux_join_of[device], 0), "hipStreamWaitEvent(join)"))) return rc;
 	{
 		GsrProfScope p(s, "depth_sort");
 		if (fourth) gsr_radix_sort_passes(a.g.depth_keys, a.g.perm, a.g.depth_keys_alt, a.g.perm_alt, (size_t)P, 32, 4, 3, 1, a.g.sort_table, bias, s);

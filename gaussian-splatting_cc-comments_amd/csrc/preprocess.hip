@@ -33,17 +33,20 @@ __device__ __forceinline__ float gsr_sh_channel(int deg, const float* sh, int ch
 	return result + 0.5f;
 }
 
+// The stage is two kernels over the same Gaussians, independent of each other:
+//   gsr_preprocess_kernel        geometry: projection, covariance, conic, radius, tile rectangle, depth key, instance count
+//                                (44 B in, 56 B out per Gaussian; the depth sort and the instance count wait for it)
+//   gsr_preprocess_color_kernel  view-dependent colour from the SH rows (204 B in, 49 B out): needed by nothing before the
+//                                blend, so api.hip runs it on a helper stream beside the geometry kernel and the depth sort
+// Both write disjoint fields of the 48-byte splat record.  Precomputed colours need no second kernel.
+//
 // LEAF: the inputs are the optimiser's raw leaves (gsr_internal.h); activations happen here.
 template <bool LEAF>
-__global__ void __launch_bounds__(GSR_PREPROCESS_BLOCK) gsr_preprocess_kernel(GsrPreprocessArgs a, int sh_via_lds, uint32_t* __restrict__ clear, size_t clear_words)
+__global__ void __launch_bounds__(GSR_PREPROCESS_BLOCK) gsr_preprocess_kernel(GsrPreprocessArgs a, uint32_t* __restrict__ clear, size_t clear_words)
 {
-	// staging of the wave's SH block: the packed layout passes through in two halves of 32 rows (6.6 KB per wave, so that
-	// 4 waves per SIMD fit), the split leaf tensors as one linear 12 KB block
-	__shared__ float4 s_sh[GSR_PREPROCESS_BLOCK / 64][(LEAF ? 64 : 32) * GSR_SH_ROW4];
 	const int idx = blockIdx.x * GSR_PREPROCESS_BLOCK + threadIdx.x;
-	// The Gaussian's own inputs first, unconditionally (a culled Gaussian wastes 44 bytes): issued ahead of the SH
-	// block, every load of the wave is in flight at once -- one memory round trip instead of three dependent ones
-	// (position -> cull test -> scale / rotation / opacity)
+	// The Gaussian's inputs, unconditionally (a culled Gaussian wastes 44 bytes): every load of the wave is in flight at
+	// once -- one memory round trip instead of three dependent ones (position -> cull test -> scale / rotation / opacity)
 	GsrVec3 p_orig = {0.f, 0.f, 0.f};
 	float sc[3] = {0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f}, cov_in[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 	float col_in[3] = {0.f, 0.f, 0.f}, opac = 0.f;
@@ -58,29 +61,6 @@ __global__ void __launch_bounds__(GSR_PREPROCESS_BLOCK) gsr_preprocess_kernel(Gs
 		}
 		opac = a.opacities[idx];
 		if (a.colors_precomp) { col_in[0] = a.colors_precomp[3 * idx]; col_in[1] = a.colors_precomp[3 * idx + 1]; col_in[2] = a.colors_precomp[3 * idx + 2]; }
-	}
-	// The wave's 64 x 48 SH floats are contiguous in HBM: stage them into LDS with coalesced float4
-	// loads (a lane reading its own 192-byte row makes every load instruction touch 64 lines)
-	float row[48];  // the lane's own SH row (registers: only ever indexed with constants)
-	if (sh_via_lds) {
-		const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-		const int wave_first = blockIdx.x * GSR_PREPROCESS_BLOCK + wave * 64;
-		const int nrows = min(64, a.P - wave_first);
-		if (LEAF) {
-			if (nrows > 0) gsr_sh_lin_load(reinterpret_cast<float*>(s_sh[wave]), a.shs, a.shs_rest, wave_first, nrows, lane);
-			__builtin_amdgcn_wave_barrier();
-			gsr_sh_lin_row_get(reinterpret_cast<const float*>(s_sh[wave]), lane, row);
-		} else {
-			float4 v[12];
-			gsr_sh_rows_fetch(v, a.shs, wave_first, max(nrows, 0), lane);  // all twelve loads in flight at once
-#pragma unroll
-			for (int half = 0; half < 2; half++) {
-				gsr_sh_rows_commit_half(s_sh[wave], v, nrows, lane, half);
-				__builtin_amdgcn_wave_barrier();
-				if ((lane >> 5) == half) gsr_sh_row_get(s_sh[wave], lane & 31, row);
-				__builtin_amdgcn_wave_barrier();
-			}
-		}
 	}
 	uint32_t tiles = 0;
 	uint2 rect = make_uint2(0u, 0u);
@@ -130,56 +110,20 @@ __global__ void __launch_bounds__(GSR_PREPROCESS_BLOCK) gsr_preprocess_kernel(Gs
 			gsr_get_rect(pix, piy, gsr_f2i(my_radius), gx, gy, minx, miny, maxx, maxy);
 			if ((maxx - minx) * (maxy - miny) == 0) break;
 
-			float rgb[3];
-			uint8_t clamp_bits = 0;
-			if (a.colors_precomp) {
-				rgb[0] = col_in[0]; rgb[1] = col_in[1]; rgb[2] = col_in[2];
-			} else {
-				float dx = p_orig.x - a.cam_pos[0], dy = p_orig.y - a.cam_pos[1], dz = p_orig.z - a.cam_pos[2];
-				float len = sqrtf(dx * dx + dy * dy + dz * dz);
-				dx = dx / len; dy = dy / len; dz = dz / len;
-				const float* sh = a.shs + (size_t)idx * a.M * 3;
-				float raw[3], ddir9[9];
-				if (sh_via_lds) {
-#pragma unroll
-					for (int ch = 0; ch < 3; ch++) raw[ch] = gsr_sh_channel(a.D, row, ch, dx, dy, dz);
-					gsr_sh_ddir9(a.D, row, dx, dy, dz, ddir9);
-				} else {
-					float sh_local[48];
-					if (LEAF) {  // generic M / unaligned leaves: gather the used rows (rare path)
-						const int used = (a.D + 1) * (a.D + 1);
-#pragma unroll
-						for (int k = 0; k < 16; k++)  // constant indices (registers, no scratch); (D+1)^2 <= 16
-							if (k < used) {
-#pragma unroll
-								for (int ch = 0; ch < 3; ch++)
-									sh_local[k * 3 + ch] = k == 0 ? a.shs[3 * (size_t)idx + ch] : a.shs_rest[((size_t)idx * (a.M - 1) + (k - 1)) * 3 + ch];
-							}
-						sh = sh_local;
-					}
-#pragma unroll
-					for (int ch = 0; ch < 3; ch++) raw[ch] = gsr_sh_channel(a.D, sh, ch, dx, dy, dz);
-					gsr_sh_ddir9(a.D, sh, dx, dy, dz, ddir9);
-				}
-				// what the backward needs from the SH row, so that it never reads the row again (36 B instead of 192 B)
-#pragma unroll
-				for (int k = 0; k < 9; k++) a.g.sh_ddir[(size_t)k * a.P + idx] = ddir9[k];  // nine planes: each store instruction is one contiguous run
-#pragma unroll
-				for (int ch = 0; ch < 3; ch++) {
-					const float v = raw[ch];
-					if (v < 0) clamp_bits |= (uint8_t)(1u << ch);
-					rgb[ch] = fmaxf(v, 0.0f);
-				}
-			}
 			tiles = (uint32_t)((maxy - miny) * (maxx - minx));
 			radius_out = gsr_f2i(my_radius);
 			depth_key = __float_as_uint(p_view.z);  // > 0.2, so unsigned order == float order
-			a.g.clamped[idx] = clamp_bits;
-			float4* rec = reinterpret_cast<float4*>(a.g.splat + idx);
-			rec[0] = make_float4(pix, piy, conic_a, conic_b);
-			rec[1] = make_float4(conic_c, LEAF ? gsr_act_sigmoid(opac) : opac, rgb[0], rgb[1]);
 			rect = make_uint2((uint32_t)minx | ((uint32_t)miny << 16), (uint32_t)(maxx - minx) | ((uint32_t)(maxy - miny) << 16));
-			rec[2] = make_float4(rgb[2], 0.f, __uint_as_float(rect.x), __uint_as_float(rect.y));
+			// the record's fields other than the colour (GsrSplat: x, y, conic a, b | conic c, opacity, r, g | b, -, rect)
+			float* rec = reinterpret_cast<float*>(a.g.splat + idx);
+			*reinterpret_cast<float4*>(rec) = make_float4(pix, piy, conic_a, conic_b);
+			*reinterpret_cast<float2*>(rec + 4) = make_float2(conic_c, LEAF ? gsr_act_sigmoid(opac) : opac);
+			*reinterpret_cast<float2*>(rec + 10) = make_float2(__uint_as_float(rect.x), __uint_as_float(rect.y));
+			if (a.colors_precomp) {
+				*reinterpret_cast<float2*>(rec + 6) = make_float2(col_in[0], col_in[1]);
+				rec[8] = col_in[2];
+				a.g.clamped[idx] = 0;
+			}
 		} while (0);
 		if (a.radii) a.radii[idx] = radius_out;  // optional, cuda_rasterizer/rasterizer.h:52
 		a.g.tiles_touched[idx] = tiles;
@@ -221,18 +165,109 @@ __global__ void __launch_bounds__(GSR_PREPROCESS_BLOCK) gsr_preprocess_kernel(Gs
 		clear[w] = 0u;
 }
 
+// View-dependent colour (forward.cu:21-81, called at :306-312): colour = clamp0(SH(dir) + 0.5) into the record, the
+// clamp flags, and the nine derivatives d colour / d direction the backward needs (so that it never reads the 192-byte row
+// again).  Done for every Gaussian in front of the near plane -- a superset of those the geometry kernel keeps (it
+// also drops det == 0 and empty rectangles); what is written for the difference is never read.
+template <bool LEAF>
+__global__ void __launch_bounds__(GSR_PREPROCESS_BLOCK) gsr_preprocess_color_kernel(GsrPreprocessArgs a, int sh_via_lds)
+{
+	// staging of the wave's SH block: the packed layout passes through in two halves of 32 rows (6.6 KB per wave, so that
+	// 4 waves per SIMD fit), the split leaf tensors as one linear 12 KB block
+	__shared__ float4 s_sh[GSR_PREPROCESS_BLOCK / 64][(LEAF ? 64 : 32) * GSR_SH_ROW4];
+	const int idx = blockIdx.x * GSR_PREPROCESS_BLOCK + threadIdx.x;
+	GsrVec3 p_orig = {0.f, 0.f, 0.f};
+	if (idx < a.P) { p_orig.x = a.means3D[3 * idx]; p_orig.y = a.means3D[3 * idx + 1]; p_orig.z = a.means3D[3 * idx + 2]; }
+	// The wave's 64 x 48 SH floats are contiguous in HBM: stage them into LDS with coalesced float4
+	// loads (a lane reading its own 192-byte row makes every load instruction touch 64 lines)
+	float row[48];  // the lane's own SH row (registers: only ever indexed with constants)
+	if (sh_via_lds) {
+		const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+		const int wave_first = blockIdx.x * GSR_PREPROCESS_BLOCK + wave * 64;
+		const int nrows = min(64, a.P - wave_first);
+		if (LEAF) {
+			if (nrows > 0) gsr_sh_lin_load(reinterpret_cast<float*>(s_sh[wave]), a.shs, a.shs_rest, wave_first, nrows, lane);
+			__builtin_amdgcn_wave_barrier();
+			gsr_sh_lin_row_get(reinterpret_cast<const float*>(s_sh[wave]), lane, row);
+		} else {
+			float4 v[12];
+			gsr_sh_rows_fetch(v, a.shs, wave_first, max(nrows, 0), lane);  // all twelve loads in flight at once
+#pragma unroll
+			for (int half = 0; half < 2; half++) {
+				gsr_sh_rows_commit_half(s_sh[wave], v, nrows, lane, half);
+				__builtin_amdgcn_wave_barrier();
+				if ((lane >> 5) == half) gsr_sh_row_get(s_sh[wave], lane & 31, row);
+				__builtin_amdgcn_wave_barrier();
+			}
+		}
+	}
+	if (idx >= a.P) return;
+	if (gsr_transform_point_4x3(p_orig, a.viewmatrix).z <= 0.2f) return;  // the geometry kernel's near-plane test, same expression
+
+	float dx = p_orig.x - a.cam_pos[0], dy = p_orig.y - a.cam_pos[1], dz = p_orig.z - a.cam_pos[2];
+	float len = sqrtf(dx * dx + dy * dy + dz * dz);
+	dx = dx / len; dy = dy / len; dz = dz / len;
+	const float* sh = a.shs + (size_t)idx * a.M * 3;
+	float raw[3], ddir9[9];
+	if (sh_via_lds) {
+#pragma unroll
+		for (int ch = 0; ch < 3; ch++) raw[ch] = gsr_sh_channel(a.D, row, ch, dx, dy, dz);
+		gsr_sh_ddir9(a.D, row, dx, dy, dz, ddir9);
+	} else {
+		float sh_local[48];
+		if (LEAF) {  // generic M / unaligned leaves: gather the used rows (rare path)
+			const int used = (a.D + 1) * (a.D + 1);
+#pragma unroll
+			for (int k = 0; k < 16; k++)  // constant indices (registers, no scratch); (D+1)^2 <= 16
+				if (k < used) {
+#pragma unroll
+					for (int ch = 0; ch < 3; ch++)
+						sh_local[k * 3 + ch] = k == 0 ? a.shs[3 * (size_t)idx + ch] : a.shs_rest[((size_t)idx * (a.M - 1) + (k - 1)) * 3 + ch];
+				}
+			sh = sh_local;
+		}
+#pragma unroll
+		for (int ch = 0; ch < 3; ch++) raw[ch] = gsr_sh_channel(a.D, sh, ch, dx, dy, dz);
+		gsr_sh_ddir9(a.D, sh, dx, dy, dz, ddir9);
+	}
+#pragma unroll
+	for (int k = 0; k < 9; k++) a.g.sh_ddir[(size_t)k * a.P + idx] = ddir9[k];  // nine planes: each store instruction is one contiguous run
+	uint8_t clamp_bits = 0;
+	float rgb[3];
+#pragma unroll
+	for (int ch = 0; ch < 3; ch++) {
+		const float v = raw[ch];
+		if (v < 0) clamp_bits |= (uint8_t)(1u << ch);
+		rgb[ch] = fmaxf(v, 0.0f);
+	}
+	a.g.clamped[idx] = clamp_bits;
+	float* rec = reinterpret_cast<float*>(a.g.splat + idx);
+	*reinterpret_cast<float2*>(rec + 6) = make_float2(rgb[0], rgb[1]);
+	rec[8] = rgb[2];
+}
+
 void gsr_launch_preprocess(const GsrPreprocessArgs& a, hipStream_t s)
 {
 	const int nb = (a.P + GSR_PREPROCESS_BLOCK - 1) / GSR_PREPROCESS_BLOCK;
 	uint32_t* clear = (uint32_t*)a.g.sort_table;
 	const size_t clear_words = gsr_radix_clear_words((size_t)a.P);
+	if (a.leaf) hipLaunchKernelGGL(gsr_preprocess_kernel<true>, dim3(nb), dim3(GSR_PREPROCESS_BLOCK), 0, s, a, clear, clear_words);
+	else hipLaunchKernelGGL(gsr_preprocess_kernel<false>, dim3(nb), dim3(GSR_PREPROCESS_BLOCK), 0, s, a, clear, clear_words);
+}
+
+// the colour kernel exists only for SH colours
+bool gsr_preprocess_needs_color(const GsrPreprocessArgs& a) { return a.shs && !a.colors_precomp; }
+
+void gsr_launch_preprocess_color(const GsrPreprocessArgs& a, hipStream_t s)
+{
+	const int nb = (a.P + GSR_PREPROCESS_BLOCK - 1) / GSR_PREPROCESS_BLOCK;
 	// LDS-transposed SH path: the flagship layout (16 coefficients), 16-byte aligned tensor
-	int sh_via_lds = (a.shs && !a.colors_precomp && a.M == 16 && ((uintptr_t)a.shs & 15u) == 0) ? 1 : 0;
+	int sh_via_lds = (a.M == 16 && ((uintptr_t)a.shs & 15u) == 0) ? 1 : 0;
 	if (a.leaf) {
 		if (((uintptr_t)a.shs_rest & 15u) != 0) sh_via_lds = 0;
-		hipLaunchKernelGGL(gsr_preprocess_kernel<true>, dim3(nb), dim3(GSR_PREPROCESS_BLOCK), 0, s, a, sh_via_lds, clear, clear_words);
+		hipLaunchKernelGGL(gsr_preprocess_color_kernel<true>, dim3(nb), dim3(GSR_PREPROCESS_BLOCK), 0, s, a, sh_via_lds);
 	} else {
-		hipLaunchKernelGGL(gsr_preprocess_kernel<false>, dim3(nb), dim3(GSR_PREPROCESS_BLOCK), 0, s, a, sh_via_lds, clear, clear_words);
+		hipLaunchKernelGGL(gsr_preprocess_color_kernel<false>, dim3(nb), dim3(GSR_PREPROCESS_BLOCK), 0, s, a, sh_via_lds);
 	}
 }
 

@@ -104,6 +104,11 @@ int gsr_binning_layout_of(int P, int64_t num_rendered, int width, int height, gs
  * until `*num_rendered_host` is valid.
  *   radii [P] int32 out (0 for culled Gaussians), or NULL when the caller does not want them
  *   (`int* radii = nullptr`, cuda_rasterizer/rasterizer.h:52); geometry: gsr_geometry_bytes(P) bytes.
+ * Streams: all work is ordered after what `stream` holds on entry and is complete, in `stream`'s order, for whatever
+ * the caller enqueues after the call.  Inside the call the SH colour kernel runs on a helper stream of the library (one
+ * per host thread and device, non-blocking, forked from and joined into `stream` with events) beside the geometry
+ * kernel and the depth sort; GSR_SERIAL=1 in the environment, debug != 0 and an all-stages gsr_profile_begin() keep
+ * it on `stream`.
  */
 int gsr_forward_preprocess(
 	int P, int D, int M,

@@ -191,6 +191,39 @@ def test_band_culling_changes_nothing(case):
             os.environ["GSR_NO_CULL"] = prev
 
 
+def test_colour_kernel_beside_or_in_line_is_the_same():
+    """The SH colour kernel of the forward runs on a helper stream beside the geometry kernel and the depth sort, forked
+    from and joined into the caller's stream inside gsr_forward_preprocess (api.hip).  GSR_SERIAL=1 runs it in line.
+    Both must give bit-identical images, state and gradients -- also when calls follow each other without a host sync in
+    between and reuse the same buffers (a missed join would show as a stale colour in the next blend)."""
+    _need_gpu()
+    dev = torch.device("cuda:0")
+    scene, cam, D = gsr_scene.make_config("C2")
+    dpix = torch.randn(3, cam.image_height, cam.image_width, generator=torch.Generator().manual_seed(1)).to(dev)
+    prev = os.environ.get("GSR_SERIAL")
+    try:
+        os.environ["GSR_SERIAL"] = "1"
+        ref = _direct(scene, cam, D, dpix, dev)
+        os.environ["GSR_SERIAL"] = "0"
+        for _ in range(5):   # back to back: the caching allocator hands the same buffers to consecutive calls
+            _same(ref, _direct(scene, cam, D, dpix, dev))
+        # a second scene in between changes every colour: nothing of it may survive into the next call
+        scene2 = gsr_scene.make_scene(scene.means3D.shape[0], -2.2, sh_degree=D, seed=7)
+        _direct(scene2, cam, D, dpix, dev)
+        _same(ref, _direct(scene, cam, D, dpix, dev))
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            got = _direct(scene, cam, D, dpix, dev)
+        side.synchronize()
+        _same(ref, got)
+    finally:
+        if prev is None:
+            os.environ.pop("GSR_SERIAL", None)
+        else:
+            os.environ["GSR_SERIAL"] = prev
+
+
 def test_bench_gpus_2_on_one_gpu_over_gloo():
     """`python bench.py --gpus 2` with no launcher starts two ranks itself; here both share the one GPU of the box and
     exchange over gloo (GSR_BENCH_BACKEND=gloo) -- the rehearsal of the view-parallel step (rasterize_view_parallel,
