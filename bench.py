@@ -573,7 +573,9 @@ def run_rank(args, rank, world, dev):
                roofline=roofline, kernels=kern,
                kernels_note=f"per-kernel ms: HIP events on the launch stream; '{DOMINANT_STAGE}' over the timed region, the "
                             f"others over {table_steps} extra untimed steps (bracketing every stage inside the timed region "
-                            "would add ~80 us of event drains per step)")
+                            "would add ~80 us of event drains per step); 'preprocess_color' is timed in line here -- in the "
+                            "timed region it runs on the library's helper stream beside 'preprocess' and 'depth_sort', so the "
+                            "kernels add up to more than the step")
     if world == 1 and not args.no_extras:
         out["loss_l1_ssim"] = bench_loss(state["color"].detach(), dev)
         if not args.no_train_step:
