@@ -83,10 +83,8 @@ __global__ void __launch_bounds__(GSR_PREPROCESS_BLOCK) gsr_duplicate_keys_kerne
 		clear[w] = 0u;
 	const uint32_t* __restrict__ perm = g.status[2] ? g.perm_alt : g.perm;  // where the depth sort left its result
 	__shared__ uint32_t lds[GSR_PREPROCESS_BLOCK / 64];
-	__shared__ uint32_t s_start[GSR_PREPROCESS_BLOCK / 64][65];  // start offset of each lane's run, relative to the wave's
-	__shared__ uint32_t s_rect[GSR_PREPROCESS_BLOCK / 64][64];   // minx | miny << 16
-	__shared__ uint32_t s_w[GSR_PREPROCESS_BLOCK / 64][64];
-	__shared__ uint32_t s_idx[GSR_PREPROCESS_BLOCK / 64][64];
+	__shared__ uint4 s_own[GSR_PREPROCESS_BLOCK / 64][64];       // per Gaussian: start, minx | miny << 16, rectangle width, id
+	__shared__ uint32_t s_flag[GSR_PREPROCESS_BLOCK / 64][64];   // per position of the current row: lane + 1 of the Gaussian that starts there
 	const int i = blockIdx.x * GSR_PREPROCESS_BLOCK + threadIdx.x;
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	uint32_t idx = 0, tiles = 0, rmin = 0, w = 1;
@@ -124,26 +122,49 @@ __global__ void __launch_bounds__(GSR_PREPROCESS_BLOCK) gsr_duplicate_keys_kerne
 	if (tiles) g.slot_base[idx] = off;
 	const uint32_t wave_first = __shfl(off, 0, 64);
 	const uint32_t wave_total = __shfl(incl, 63, 64) - wave_first;
-	s_start[wave][lane] = off - wave_first;
-	if (lane == 63) s_start[wave][64] = wave_total;
-	s_rect[wave][lane] = rmin;
-	s_w[wave][lane] = w;
-	s_idx[wave][lane] = idx;
+	s_own[wave][lane] = make_uint4(off - wave_first, rmin, w, idx);
 	__builtin_amdgcn_wave_barrier();
-	const uint32_t* start = s_start[wave];
-	for (uint32_t j = lane; j < wave_total; j += 64) {
-		// owner = last lane whose start <= j (lanes with no tiles share their successor's start and are skipped)
-		uint32_t lo = 0, hi = 64;  // invariant: start[lo] <= j < start[hi]
-#pragma unroll
-		for (int step = 0; step < 6; step++) {
-			const uint32_t mid = (lo + hi) >> 1;
-			if (start[mid] <= j) lo = mid; else hi = mid;
+	// Owner of every position of a row of 64: the Gaussians whose run starts inside the row flag their first position with
+	// their lane number (two Gaussians with tiles never share a start), the lanes -- now as positions -- take the running
+	// maximum of the flags in front of them (six DPP steps), and positions in front of the row's first flag continue the
+	// Gaussian the previous row ended in.  (A binary search over the 64 starts cost six dependent LDS reads per row.)
+	const uint32_t mystart = off - wave_first;
+	uint32_t carry = 0u;  // lane + 1 of the Gaussian that owns the position in front of the row
+	for (uint32_t j0 = 0; j0 < wave_total; j0 += 64) {
+		s_flag[wave][lane] = 0u;
+		__builtin_amdgcn_wave_barrier();
+		const uint32_t rel = mystart - j0;
+		if (tiles && rel < 64u) s_flag[wave][rel] = (uint32_t)lane + 1u;
+		__builtin_amdgcn_wave_barrier();
+		uint32_t o = s_flag[wave][lane];
+		o = max(o, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)o, 0x111, 0xF, 0xF, false));  // row_shr:1
+		o = max(o, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)o, 0x112, 0xF, 0xF, false));  // row_shr:2
+		o = max(o, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)o, 0x114, 0xF, 0xF, false));  // row_shr:4
+		o = max(o, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)o, 0x118, 0xF, 0xF, false));  // row_shr:8  -> running maximum inside each row of 16
+		o = max(o, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)o, 0x142, 0xA, 0xF, false));  // row_bcast:15 into rows 1, 3
+		o = max(o, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)o, 0x143, 0xC, 0xF, false));  // row_bcast:31 into rows 2, 3
+		o = max(o, carry);
+		carry = (uint32_t)__builtin_amdgcn_readlane((int)o, 63);
+		__builtin_amdgcn_wave_barrier();
+		const uint32_t j = j0 + lane;
+		if (j >= wave_total) continue;
+		const uint32_t lo = o - 1u;
+		const uint4 own = s_own[wave][lo];  // one 16-byte LDS read
+		const uint32_t k = j - own.x;
+		const uint32_t rm = own.y, ww = own.z;
+		// row of the rectangle = k / ww: k < tiles and ww <= 65535.  Below 2^22 the float quotient is off by at most one, which
+		// the remainder test repairs (a 32-bit integer division is ~25 instructions); larger rectangles take the division
+		uint32_t q;
+		if (k < (1u << 22)) {
+			q = (uint32_t)((float)k * __builtin_amdgcn_rcpf((float)ww));
+			const int32_t r = (int32_t)(k - q * ww);
+			q = r < 0 ? q - 1u : (r >= (int32_t)ww ? q + 1u : q);
+		} else {
+			q = k / ww;
 		}
-		const uint32_t k = j - start[lo];
-		const uint32_t rm = s_rect[wave][lo], ww = s_w[wave][lo];
-		const uint32_t y = (rm >> 16) + k / ww, x = (rm & 0xffffu) + k % ww;
+		const uint32_t y = (rm >> 16) + q, x = (rm & 0xffffu) + (k - q * ww);
 		keys[wave_first + j] = y * gx + x;
-		vals[wave_first + j] = s_idx[wave][lo];
+		vals[wave_first + j] = own.w;
 	}
 }
 
