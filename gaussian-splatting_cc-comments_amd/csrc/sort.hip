@@ -128,7 +128,7 @@ __global__ void __launch_bounds__(GSR_SORT_THREADS) gsr_radix_scatter_kernel(
 	__shared__ uint32_t wsum[GSR_SORT_THREADS / 64];
 	constexpr int TILE = GSR_SORT_THREADS * ITEMS;
 	__shared__ __attribute__((aligned(16))) uint32_t sstage[2 * TILE];  // the block's elements in digit order; before that, the offset walk's partial sums
-	static_assert(2 * TILE >= 2 * (GSR_SORT_THREADS / 64) * GSR_SORT_RADIX, "the walk's partial sums must fit the staging area");
+	static_assert(2 * TILE >= 2 * (GSR_SORT_THREADS / 64) * GSR_SORT_RADIX, "the walk's partial sums and the ranking's peer masks must fit the staging area");
 	uint32_t* const skey = sstage;
 	uint32_t* const sval = sstage + TILE;
 	__shared__ uint32_t s_bias[2];
@@ -255,27 +255,41 @@ __global__ void __launch_bounds__(GSR_SORT_THREADS) gsr_radix_scatter_kernel(
 	const GsrKeyBias kb = gsr_sort_bias(bias, s_bias);  // (contains the barrier that also publishes wsum's readers' results)
 	__syncthreads();
 
+	// In-wave ranking.  The lanes that hold digit d in a round find each other through LDS: every lane ORs its bit into the
+	// wave's 64-bit word of d (ds_or_b64) and reads the word back -- the set of its peers, for ~10 vector instructions per element
+	// where seven ballots with their 64-bit selects cost ~60 (the kernel ran at 73 % of the VALU issue rate).  A wave's LDS
+	// operations execute in program order, so the read sees every lane's OR, and the first peer's updates (digit count, mask
+	// back to zero) come after every peer's reads.  The words live in the staging area, which is not in use yet.
 	uint32_t* mycount = wcount[wave];
+	unsigned long long* mymask = reinterpret_cast<unsigned long long*>(sstage) + wave * GSR_SORT_RADIX;
+	{
+		uint4* z = reinterpret_cast<uint4*>(mymask);  // 256 words of 8 bytes = 128 uint4 per wave
+		z[lane] = make_uint4(0u, 0u, 0u, 0u);
+		z[64 + lane] = make_uint4(0u, 0u, 0u, 0u);
+	}
+	__builtin_amdgcn_wave_barrier();
+	const unsigned long long lanebit = 1ull << lane;
 #pragma unroll
 	for (int it = 0; it < ITEMS; it++) {
 		const size_t i = gsr_sort_index<ITEMS>(blockIdx.x, wave, it, lane);
 		const bool valid = i < n;
 		const uint32_t d = (gsr_sort_key(key[it], kb, biased) >> shift) & mask;
-		unsigned long long peers = __builtin_amdgcn_ballot_w64(valid);
-		for (int b = 0; b < nbits; b++) {
-			const bool bit = (d >> b) & 1u;
-			const unsigned long long m = __builtin_amdgcn_ballot_w64(bit);
-			peers &= bit ? m : ~m;
-		}
-		// peers = valid lanes of this wave holding digit d in this round; lowest one is the leader
-		const int leader = __ffsll((long long)peers) - 1;
+		unsigned long long peers = lanebit;
 		uint32_t old = 0;
-		if (valid && lane == leader) {
-			old = mycount[d];
-			mycount[d] = old + (uint32_t)__popcll(peers);
+		if (valid) {
+			atomicOr(&mymask[d], lanebit);
+			__builtin_amdgcn_wave_barrier();
+			peers = __atomic_load_n(&mymask[d], __ATOMIC_RELAXED);
+			old = __atomic_load_n(&mycount[d], __ATOMIC_RELAXED);
 		}
-		old = __shfl(old, leader < 0 ? 0 : leader, 64);
-		rank[it] = old + (uint32_t)__popcll(peers & ((1ull << lane) - 1ull));
+		__builtin_amdgcn_wave_barrier();
+		const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(peers >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)peers, 0u));  // peers in lower lanes
+		if (valid && below == 0u) {  // the first peer
+			__atomic_store_n(&mycount[d], old + (uint32_t)__popcll(peers), __ATOMIC_RELAXED);
+			__atomic_store_n(&mymask[d], 0ull, __ATOMIC_RELAXED);
+		}
+		__builtin_amdgcn_wave_barrier();
+		rank[it] = old + below;
 	}
 	__syncthreads();
 	// per digit (thread d): block total -> exclusive scan over digits = local base of the digit inside
