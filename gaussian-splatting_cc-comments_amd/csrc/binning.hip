@@ -229,11 +229,21 @@ __global__ void __launch_bounds__(256) gsr_tile_ranges_kernel(const uint32_t* __
 // forward's upper bound, before anything is known about where its pixels saturate)
 __device__ __forceinline__ uint32_t gsr_tile_work_bin(const uint2* __restrict__ ranges, const uint32_t* __restrict__ tile_max_contrib, uint32_t t)
 {
+#ifdef GSR_TILE_CLOCK
+	if (!ranges) return GSR_ORDER_BINS - 1 - min(tile_max_contrib[t] >> 4, (uint32_t)GSR_ORDER_BINS - 1);  // diagnostic twin: a key supplied by the tool
+#endif
 	const uint2 r = ranges[t];
 	uint32_t work = r.y - r.x;
 	if (tile_max_contrib) work = min(work, tile_max_contrib[t]);
 	return GSR_ORDER_BINS - 1 - min(work >> 4, (uint32_t)GSR_ORDER_BINS - 1);  // bin 0 = most work
 }
+
+#ifdef GSR_TILE_CLOCK
+// diagnostic twin only (tools/tile_clock.py --oracle-key): dispatch the backward by a key the tool supplies (e.g. the
+// durations it measured in the previous step), to bound what a better work estimate could be worth
+static uint32_t* g_debug_backward_key = nullptr;
+extern "C" int gsr_debug_backward_key(uint32_t* key) { g_debug_backward_key = key; return 0; }
+#endif
 
 __global__ void __launch_bounds__(1024) gsr_tile_order_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ tile_max_contrib,
                                                               uint32_t ntiles, uint32_t* __restrict__ order)
@@ -289,8 +299,12 @@ __global__ void __launch_bounds__(1024) gsr_tile_order_kernel(const uint2* __res
 
 void gsr_launch_tile_order(GsrImage img, int ntiles, bool backward, hipStream_t s)
 {
-	hipLaunchKernelGGL(gsr_tile_order_kernel, dim3(1), dim3(1024), 0, s, img.ranges, backward ? img.tile_max_contrib : (const uint32_t*)nullptr,
-	                   (uint32_t)ntiles, img.tile_order);
+	const uint32_t* key = backward ? img.tile_max_contrib : (const uint32_t*)nullptr;
+	const uint2* ranges = img.ranges;
+#ifdef GSR_TILE_CLOCK
+	if (backward && g_debug_backward_key) { key = g_debug_backward_key; ranges = nullptr; }
+#endif
+	hipLaunchKernelGGL(gsr_tile_order_kernel, dim3(1), dim3(1024), 0, s, ranges, key, (uint32_t)ntiles, img.tile_order);
 }
 
 void gsr_launch_tile_ranges(const uint32_t* tile_keys, int64_t R, uint2* ranges, int ntiles, uint32_t* valid, hipStream_t s)
