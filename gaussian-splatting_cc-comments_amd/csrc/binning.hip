@@ -239,7 +239,7 @@ __device__ __forceinline__ uint32_t gsr_tile_work_bin(const uint2* __restrict__ 
 }
 
 #ifdef GSR_TILE_CLOCK
-// diagnostic twin only (tools/tile_clock.py --oracle-key): dispatch the backward by a key the tool supplies (e.g. the
+// diagnostic twin only (tools/tile_clock.py --measured-key): dispatch the backward by a key the tool supplies (e.g. the
 // durations it measured in the previous step), to bound what a better work estimate could be worth
 static uint32_t* g_debug_backward_key = nullptr;
 extern "C" int gsr_debug_backward_key(uint32_t* key) { g_debug_backward_key = key; return 0; }

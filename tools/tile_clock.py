@@ -84,7 +84,7 @@ def main():
     ap.add_argument("--config", default="C3")
     ap.add_argument("--out", default=None)
     ap.add_argument("--dump", default=None, help="npz with the raw clocks and the dispatch keys")
-    ap.add_argument("--oracle-key", action="store_true", help="also dispatch the backward by its own measured durations")
+    ap.add_argument("--measured-key", action="store_true", help="also dispatch the backward by its own measured durations")
     a = ap.parse_args()
     if not os.path.exists(TWIN):
         raise SystemExit(f"{TWIN} missing: make -C gaussian-splatting_cc-comments_amd/csrc tile_clock")
@@ -153,7 +153,7 @@ def main():
     print(f"== dispatch keys: rank correlation with the wave's duration: forward, range length {rc(length, fd):.2f}; "
           f"backward, staged instances {rc(staged, bd):.2f}; forward duration vs backward duration {rc(fd, bd):.2f}; "
           f"largest n_contrib vs forward duration {rc(tmc, fd):.2f}", file=out)
-    if a.oracle_key:
+    if a.measured_key:
         # Is a better dispatch key to be had?  Dispatch the backward by the durations just measured (three rounds: the durations
         # change with the order) and compare the launch spans.  (Measured at C3: 543 us with the product key, 629 / 594 / 592
         # by durations -- a wave's duration says more about its neighbours than about its tile; and by the kernel's own count
