@@ -27,9 +27,15 @@
 // there are CUs with 16 serial ranking rounds each (measured 18 us per pass at P = 1M).
 // Swept on MI355X for the instance sort: 8 / 16 / 32 items -> 0.168 / 0.166 / 0.216 ms at R = 9.2M (C3)
 // and 1.52 / 1.43 / 1.72 ms at R = 71M (C5): 16 it is.
+#ifndef GSR_SORT_ITEMS_LARGE
 #define GSR_SORT_ITEMS_LARGE 16
+#endif
 #define GSR_SORT_ITEMS_SMALL 4
 #define GSR_SORT_SMALL_N (4u << 20)
+// ... and 32 for the largest sorts: re-swept with the LDS ranking, 12 / 16 / 24 / 32 items -> 0.124 / 0.126 / 0.136 / 0.150 ms at
+// R = 9.2M (C3) but 1.30 / 1.17 / 1.12 / 1.07 ms at R = 71M (C5), where the longer digit runs of an 8 192-element block pay
+#define GSR_SORT_ITEMS_HUGE 32
+#define GSR_SORT_HUGE_N (32u << 20)
 #ifndef GSR_WALK_ROWS
 #define GSR_WALK_ROWS 8    // rows of the offset tables a wave keeps in flight (one uint4 per lane each)
 #endif
@@ -160,7 +166,7 @@ __global__ void __launch_bounds__(GSR_SORT_THREADS) gsr_radix_scatter_kernel(
 	uint32_t my_gbase;
 	{
 		uint32_t v = 0, before = 0;
-		if constexpr (ITEMS == GSR_SORT_ITEMS_LARGE) {
+		if constexpr (ITEMS >= GSR_SORT_ITEMS_LARGE) {
 			const int my_chunk = blockIdx.x / GSR_SORT_CHUNK, my_super = my_chunk / GSR_SORT_CHUNK;
 			const bool three_level = nchunks > GSR_SORT_CHUNK;  // uniform
 			const int nS = three_level ? (nchunks + GSR_SORT_CHUNK - 1) / GSR_SORT_CHUNK : 0;
@@ -343,7 +349,7 @@ __global__ void __launch_bounds__(GSR_SORT_THREADS) gsr_radix_scatter_kernel(
 
 int gsr_radix_num_passes(int nbits_total) { return (nbits_total + 7) / 8; }
 
-static inline int gsr_sort_items(size_t n) { return n <= GSR_SORT_SMALL_N ? GSR_SORT_ITEMS_SMALL : GSR_SORT_ITEMS_LARGE; }
+static inline int gsr_sort_items(size_t n) { return n <= GSR_SORT_SMALL_N ? GSR_SORT_ITEMS_SMALL : (n < GSR_SORT_HUGE_N ? GSR_SORT_ITEMS_LARGE : GSR_SORT_ITEMS_HUGE); }
 static inline size_t gsr_sort_nblocks(size_t n) { const size_t tile = (size_t)GSR_SORT_THREADS * gsr_sort_items(n); return (n + tile - 1) / tile; }
 static inline size_t gsr_sort_nchunks(size_t n) { return (gsr_sort_nblocks(n) + GSR_SORT_CHUNK - 1) / GSR_SORT_CHUNK; }
 static inline size_t gsr_sort_nsuper(size_t n) { return (gsr_sort_nchunks(n) + GSR_SORT_CHUNK - 1) / GSR_SORT_CHUNK; }
@@ -389,7 +395,8 @@ void gsr_radix_sort_passes(uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v
 			uint32_t *ko = (p % 2 == 0) ? k1 : k0, *vo = (p % 2 == 0) ? v1 : v0;
 			uint32_t* cs = chunk_base + (size_t)p * GSR_SORT_RADIX * (nchunks + (int)gsr_sort_nsuper(n));
 			if (items == GSR_SORT_ITEMS_SMALL) gsr_radix_pass<GSR_SORT_ITEMS_SMALL>(ki, vi, ko, vo, n, shift, bits, table, cs, nchunks, bias, s);
-			else gsr_radix_pass<GSR_SORT_ITEMS_LARGE>(ki, vi, ko, vo, n, shift, bits, table, cs, nchunks, bias, s);
+			else if (items == GSR_SORT_ITEMS_LARGE) gsr_radix_pass<GSR_SORT_ITEMS_LARGE>(ki, vi, ko, vo, n, shift, bits, table, cs, nchunks, bias, s);
+			else gsr_radix_pass<GSR_SORT_ITEMS_HUGE>(ki, vi, ko, vo, n, shift, bits, table, cs, nchunks, bias, s);
 		}
 		shift += bits;
 	}
