@@ -276,6 +276,9 @@ def parse_args():
                          "region uses this mode; the other one is timed afterwards and reported under 'alt_exchange'")
     ap.add_argument("--parts", type=int, default=2, help="N > 1: parts of the per-Gaussian backward whose exchange is "
                                                          "started while the next part computes")
+    ap.add_argument("--settle-steps", type=int, default=60,
+                    help="steps run before the W warm-up steps (untimed; 0 = off): lets the device reach its steady state for "
+                         "this workload, reported as `settle` in the JSON line")
     ap.add_argument("--dry-run", action="store_true",
                     help="rehearsal of the N > 1 plumbing WITHOUT the rasterizer (no GPU needed): ranks are spawned, the "
                          "process group is formed and every step runs only the gradient exchange on synthetic buffers")
@@ -474,12 +477,21 @@ def run_rank(args, rank, world, dev):
 
     mode = args.sh_exchange
     step = steps[mode]
+    # Settling phase, untimed and before the W warm-up steps: the first ~20 steps of a fresh process run up to 7 % slower
+    # than the steady state (1.31 -> 1.22 ms at C3, decaying over ~25 ms of GPU time; a matmul loop beforehand does not
+    # remove it, steps of this workload do), so a short K would measure the ramp instead of the training loop's rate.
+    settle_steps = 0 if args.dry_run else max(0, args.settle_steps)
+    for _ in range(settle_steps):   # a count, the same on every rank (the steps of N > 1 contain collectives)
+        step()
+    sync()
     for _ in range(args.warmup):
         step()
     # Timed region: HIP events only around the dominant kernel (every event record drains the queue for
     # ~5 us; bracketing all stages costs ~80 us per step, 4 % of it) plus one event per step boundary.  The full
     # per-kernel table comes from a second, untimed pass below.
     elapsed, per_step = timed(step, args.steps, only=DOMINANT_STAGE)
+    if os.environ.get("GSR_BENCH_DUMP_STEPS") == "1" and rank == 0:
+        print("per-step ms:", " ".join(f"{x:.3f}" for x in per_step), file=sys.stderr, flush=True)
     dom_times, ktimes, table_steps = [], [], 0
     if not args.dry_run:
         dom_times = [ms for name, ms in _C.profile_end(capacity=4 * max(args.steps, 1)) if name == DOMINANT_STAGE]
@@ -503,7 +515,10 @@ def run_rank(args, rank, world, dev):
     out = dict(metric="train iters/sec (fwd+bwd rasterize) @1980x1080, 1M Gaussians", value=round(world * args.steps / elapsed, 3),
                unit="it/s", n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(ms_per_step, 4),
                higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
-               step_ms=step_stats(per_step))
+               step_ms=step_stats(per_step),
+               settle=dict(steps=settle_steps,
+                           note="untimed steps of the same workload before the W warm-up steps (device reaches its steady state: the "
+                                "first ~20 steps of a fresh process run up to 7 % slower); --settle-steps 0 disables"))
     if alt is not None:
         out["alt_exchange"] = alt
     parallelism = (f"view-parallel x{world}, one view per rank, SH gradient exchange: {mode}, backward in {args.parts} parts"
