@@ -398,6 +398,9 @@ static int gsr_forward_preprocess_impl(int P, int D, int M, int width, int heigh
 	{
 		GsrProfScope p(s, "depth_sort");
 		gsr_radix_sort_passes(a.g.depth_keys, a.g.perm, a.g.depth_keys_alt, a.g.perm_alt, (size_t)P, 32, 4, 0, 3, a.g.sort_table, bias, s);
+		// ... and so are the block sums over the three-pass result (the common case): the stream then holds work until the
+		// host, back from the wait below, has launched stage 2.  A fourth pass redoes them.
+		gsr_launch_sorted_block_sums(a.g, P, 1, s);
 	}
 	if ((rc = gsr_stage_done(s, debug, "depth_sort"))) return rc;
 	if ((rc = gsr_check_hip(hipEventSynchronize(ev), "hipEventSynchronize(num_rendered)"))) return rc;
@@ -418,11 +421,11 @@ static int gsr_forward_preprocess_impl(int P, int D, int M, int width, int heigh
 	const int fourth = (culled_value >> 24) != 0u || (kmax >= kmin && kmax - kmin == 0xFFFFFFFFu);
 	// join: everything the caller enqueues after this call comes after the colour kernel too
 	if (beside && (rc = gsr_check_hip(hipStreamWaitEvent(s, aux_join_of[device], 0), "hipStreamWaitEvent(join)"))) return rc;
-	{
+	if (fourth) {
 		GsrProfScope p(s, "depth_sort");
-		if (fourth) gsr_radix_sort_passes(a.g.depth_keys, a.g.perm, a.g.depth_keys_alt, a.g.perm_alt, (size_t)P, 32, 4, 3, 1, a.g.sort_table, bias, s);
+		gsr_radix_sort_passes(a.g.depth_keys, a.g.perm, a.g.depth_keys_alt, a.g.perm_alt, (size_t)P, 32, 4, 3, 1, a.g.sort_table, bias, s);
 		// three passes leave the order in (depth_keys_alt, perm_alt), four in (depth_keys, perm): recorded in status[2]
-		gsr_launch_sorted_block_sums(a.g, P, fourth ? 0 : 1, s);   // (their prefix sums are taken by the key emission itself)
+		gsr_launch_sorted_block_sums(a.g, P, 0, s);   // (their prefix sums are taken by the key emission itself)
 	}
 	return gsr_stage_done(s, debug, "depth_sort");
 }

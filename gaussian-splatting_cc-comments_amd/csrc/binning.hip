@@ -68,8 +68,8 @@ void gsr_launch_sorted_block_sums(GsrGeometry g, int P, int result_in_alt, hipSt
 // Thread i handles the i-th Gaussian in depth order.  Its first slot is the workgroup prefix plus
 // an in-workgroup scan, kept per Gaussian in GsrGeometry::slot_base.  The 64 Gaussians of a wave own ONE contiguous run
 // of output positions, so the wave emits cooperatively: lane l writes positions l, l+64, ... of the
-// run and finds the owning Gaussian of a position by binary search over the wave's 64 start offsets
-// (LDS).  Every store instruction then writes 64 consecutive elements, whatever the rectangle
+// run; the owning Gaussian of a position comes from head flags in LDS and a running maximum over the lanes
+// (below).  Every store instruction then writes 64 consecutive elements, whatever the rectangle
 // sizes (1 ... >2000 tiles) -- a per-Gaussian loop writes 64 scattered words per instruction
 // (measured 2.5x write amplification).  Order inside a Gaussian: y outer, x inner
 // (rasterizer_impl.cu:107-118).
