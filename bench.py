@@ -489,7 +489,13 @@ def run_rank(args, rank, world, dev):
     # Timed region: HIP events only around the dominant kernel (every event record drains the queue for
     # ~5 us; bracketing all stages costs ~80 us per step, 4 % of it) plus one event per step boundary.  The full
     # per-kernel table comes from a second, untimed pass below.
-    elapsed, per_step = timed(step, args.steps, only=DOMINANT_STAGE)
+    import gc
+    gc.collect()
+    gc.disable()   # a collection inside the timed region is a host pause of milliseconds (seen: one 4.8 ms step among 30 of 1.23)
+    try:
+        elapsed, per_step = timed(step, args.steps, only=DOMINANT_STAGE)
+    finally:
+        gc.enable()
     if os.environ.get("GSR_BENCH_DUMP_STEPS") == "1" and rank == 0:
         print("per-step ms:", " ".join(f"{x:.3f}" for x in per_step), file=sys.stderr, flush=True)
     dom_times, ktimes, table_steps = [], [], 0

@@ -70,12 +70,17 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer,
                               binningBuffer, imgBuffer)
         ctx.mark_non_differentiable(radii)
+        # no zero tensor for the (integer) radii output on the way back: autograd would fill P words per step for nothing
+        ctx.set_materialize_grads(False)
         return color, radii
 
     @staticmethod
     def backward(ctx, grad_out_color, _):
         num_rendered = ctx.num_rendered
         raster_settings = ctx.raster_settings
+        if grad_out_color is None:  # the image took no part in the loss: the zero gradient autograd would have materialised
+            grad_out_color = torch.zeros((3, int(raster_settings.image_height), int(raster_settings.image_width)),
+                                         dtype=torch.float32, device=ctx.saved_tensors[1].device)
         (colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer, binningBuffer,
          imgBuffer) = ctx.saved_tensors
 

@@ -118,6 +118,7 @@ class _RasterizeLeafGaussians(torch.autograd.Function):
         ctx.raster_settings, ctx.num_rendered, ctx.M, ctx.stats = raster_settings, R, M, stats
         ctx.save_for_backward(xyz, features_dc, features_rest, scaling, rotation, radii, geom, binning, img)
         ctx.mark_non_differentiable(radii)
+        ctx.set_materialize_grads(False)   # no zero tensor for the radii output on the way back
         return color, radii
 
     @staticmethod
@@ -126,6 +127,8 @@ class _RasterizeLeafGaussians(torch.autograd.Function):
         st, R, M = ctx.raster_settings, ctx.num_rendered, ctx.M
         xyz, features_dc, features_rest, scaling, rotation, radii, geom, binning, img = ctx.saved_tensors
         dev = xyz.device
+        if grad_color is None:
+            grad_color = torch.zeros((3, int(st.image_height), int(st.image_width)), dtype=torch.float32, device=dev)
         P = int(xyz.size(0))
         f32 = dict(dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):

@@ -196,6 +196,7 @@ class _RasterizeViewParallel(torch.autograd.Function):
         ctx.st, ctx.R, ctx.exchange, ctx.stats = st, R, exchange, stats
         ctx.save_for_backward(means3D, shs, scales, rotations, radii, geom, binning, img)
         ctx.mark_non_differentiable(radii)
+        ctx.set_materialize_grads(False)   # no zero tensor for the radii output on the way back
         return color, radii
 
     @staticmethod
@@ -204,6 +205,8 @@ class _RasterizeViewParallel(torch.autograd.Function):
         st, R, ex = ctx.st, ctx.R, ctx.exchange
         means3D, shs, scales, rotations, radii, geom, binning, img = ctx.saved_tensors
         dev = means3D.device
+        if grad_color is None:
+            grad_color = torch.zeros((3, int(st.image_height), int(st.image_width)), dtype=torch.float32, device=dev)
         P, M = int(means3D.size(0)), int(shs.size(1))
         if (P, M) != (ex.P, ex.M) or ex.leaf:
             raise RuntimeError(f"GradientExchange was built for P={ex.P}, M={ex.M}, leaf={ex.leaf}; got P={P}, M={M}")
