@@ -10,6 +10,7 @@ the per-step parameter gradients (59 floats per Gaussian) are summed over the ra
 with the next part); value = views per second over all ranks (weak scaling).  Prints ONE JSON line on rank 0.
 """
 import argparse
+import gc
 import json
 import math
 import os
@@ -458,13 +459,18 @@ def run_rank(args, rank, world, dev):
                 e = torch.cuda.Event(enable_timing=True)
                 e.record()
                 marks.append(e)
-        t0 = time.perf_counter()
-        mark()
-        for _ in range(nsteps):
-            step()
+        gc.collect()
+        gc.disable()   # a collection inside the timed region is a host pause of milliseconds (seen: one 4.8 ms step among 30 of 1.23)
+        try:
+            t0 = time.perf_counter()
             mark()
-        barrier()
-        elapsed = time.perf_counter() - t0
+            for _ in range(nsteps):
+                step()
+                mark()
+            barrier()
+            elapsed = time.perf_counter() - t0
+        finally:
+            gc.enable()
         if args.dry_run:
             per = [(b - a) * 1e3 for a, b in zip(marks[:-1], marks[1:])]
         else:
@@ -489,13 +495,7 @@ def run_rank(args, rank, world, dev):
     # Timed region: HIP events only around the dominant kernel (every event record drains the queue for
     # ~5 us; bracketing all stages costs ~80 us per step, 4 % of it) plus one event per step boundary.  The full
     # per-kernel table comes from a second, untimed pass below.
-    import gc
-    gc.collect()
-    gc.disable()   # a collection inside the timed region is a host pause of milliseconds (seen: one 4.8 ms step among 30 of 1.23)
-    try:
-        elapsed, per_step = timed(step, args.steps, only=DOMINANT_STAGE)
-    finally:
-        gc.enable()
+    elapsed, per_step = timed(step, args.steps, only=DOMINANT_STAGE)
     if os.environ.get("GSR_BENCH_DUMP_STEPS") == "1" and rank == 0:
         print("per-step ms:", " ".join(f"{x:.3f}" for x in per_step), file=sys.stderr, flush=True)
     dom_times, ktimes, table_steps = [], [], 0
