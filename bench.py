@@ -459,18 +459,13 @@ def run_rank(args, rank, world, dev):
                 e = torch.cuda.Event(enable_timing=True)
                 e.record()
                 marks.append(e)
-        gc.collect()
-        gc.disable()   # a collection inside the timed region is a host pause of milliseconds (seen: one 4.8 ms step among 30 of 1.23)
-        try:
-            t0 = time.perf_counter()
+        t0 = time.perf_counter()
+        mark()
+        for _ in range(nsteps):
+            step()
             mark()
-            for _ in range(nsteps):
-                step()
-                mark()
-            barrier()
-            elapsed = time.perf_counter() - t0
-        finally:
-            gc.enable()
+        barrier()
+        elapsed = time.perf_counter() - t0
         if args.dry_run:
             per = [(b - a) * 1e3 for a, b in zip(marks[:-1], marks[1:])]
         else:
@@ -486,6 +481,11 @@ def run_rank(args, rank, world, dev):
     # Settling phase, untimed and before the W warm-up steps: the first ~20 steps of a fresh process run up to 7 % slower
     # than the steady state (1.31 -> 1.22 ms at C3, decaying over ~25 ms of GPU time; a matmul loop beforehand does not
     # remove it, steps of this workload do), so a short K would measure the ramp instead of the training loop's rate.
+    # No cyclic garbage collection from here to the end of the timed regions: a collection is a host pause of milliseconds
+    # (seen: one 4.8 ms step among 30 of 1.23), and one that runs between the settling steps and the timed ones hands the
+    # allocator's blocks out in a new order, which restarts the ramp (measured: 1.61 -> 1.21 ms over the 20 timed steps).
+    gc.collect()
+    gc.disable()
     settle_steps = 0 if args.dry_run else max(0, args.settle_steps)
     for _ in range(settle_steps):   # a count, the same on every rank (the steps of N > 1 contain collectives)
         step()
@@ -515,6 +515,7 @@ def run_rank(args, rank, world, dev):
         e2, per2 = timed(steps[other], args.steps)
         alt = dict(mode=other, value=round(world * args.steps / e2, 3), ms_per_step=round(e2 / args.steps * 1e3, 4), step_ms=step_stats(per2))
 
+    gc.enable()
     if rank != 0:
         return
     ms_per_step = elapsed / args.steps * 1e3
