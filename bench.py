@@ -482,8 +482,9 @@ def run_rank(args, rank, world, dev):
     # than the steady state (1.31 -> 1.22 ms at C3, decaying over ~25 ms of GPU time; a matmul loop beforehand does not
     # remove it, steps of this workload do), so a short K would measure the ramp instead of the training loop's rate.
     # No cyclic garbage collection from here to the end of the timed regions: a collection is a host pause of milliseconds
-    # (seen: one 4.8 ms step among 30 of 1.23), and one that runs between the settling steps and the timed ones hands the
-    # allocator's blocks out in a new order, which restarts the ramp (measured: 1.61 -> 1.21 ms over the 20 timed steps).
+    # (seen: one 4.8 ms step among 30 of 1.23), and one that runs between the settling steps and the timed ones lets the GPU
+    # idle, which restarts the ramp (measured: 1.61 -> 1.21 ms over the 20 timed steps; it is the two instruction-bound
+    # blend kernels that run slower after an idle period, i.e. the shader clock).
     gc.collect()
     gc.disable()
     settle_steps = 0 if args.dry_run else max(0, args.settle_steps)
