@@ -13,8 +13,8 @@
 // kernel also adds each block's counts into per-CHUNK and per-SUPER-CHUNK sums (chunk = 64 consecutive blocks, super-chunk =
 // 64 chunks; two atomics per digit per block), so the scatter kernel finds its block's offset inside a digit with
 // <= #super-chunks + 63 + 63 loads per thread and no scan kernel runs in between (it was 6 us x 6 passes per step).
-// The ranking uses wave64 ballots ("which lanes hold my digit") instead of per-thread counters, so a lane's rank is
-// one popcount.
+// The in-wave ranking asks "which lanes hold my digit" through LDS (ds_or_b64 into the digit's 64-bit word, see the scatter
+// kernel), so a lane's rank among its peers is one mbcnt.
 // Keys may be biased: with a `bias` pointer the sort orders key' = key - min (culled keys 0xFFFFFFFF -> range + 1),
 // min / max taken from 64-way partial maxima left by the preprocess kernel; the depth sort then needs only the
 // passes that cover the bits of max - min (3 instead of 4 for any view whose depth range is below 2^24 float steps).
@@ -25,8 +25,8 @@
 // Elements per thread: 16 (4096 per workgroup: long, well-coalesced digit runs) for instance-sized
 // sorts; 4 for the Gaussian-sized depth sort, which would otherwise run on fewer workgroups than
 // there are CUs with 16 serial ranking rounds each (measured 18 us per pass at P = 1M).
-// Swept on MI355X for the instance sort: 8 / 16 / 32 items -> 0.168 / 0.166 / 0.216 ms at R = 9.2M (C3)
-// and 1.52 / 1.43 / 1.72 ms at R = 71M (C5): 16 it is.
+// Swept on MI355X for the instance sort (with the ballot ranking of round 1): 8 / 16 / 32 items -> 0.168 / 0.166 / 0.216 ms
+// at R = 9.2M (C3) and 1.52 / 1.43 / 1.72 ms at R = 71M (C5).
 #ifndef GSR_SORT_ITEMS_LARGE
 #define GSR_SORT_ITEMS_LARGE 16
 #endif
