@@ -224,6 +224,35 @@ def test_colour_kernel_beside_or_in_line_is_the_same():
             os.environ["GSR_SERIAL"] = prev
 
 
+def test_bench_line_carries_the_contract_fields():
+    """`python bench.py` prints ONE JSON line with the fields the task statement names, including `roofline` for the
+    dominant kernel and `cpu_baseline` (here at C1, where the CPU legs take a second)."""
+    _need_gpu()
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "C1", "--steps", "4", "--warmup", "1",
+                        "--settle-steps", "3", "--no-train-step"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 4 and d["warmup"] == 1 and d["higher_is_better"] is True
+    assert d["unit"] == "it/s" and d["dtype"] == "f32" and d["data"] == "synthetic" and d["vs_baseline"] is None
+    assert abs(d["value"] - 1e3 / d["ms_per_step"]) < 1e-2 * d["value"]
+    assert "workload" in d["config"] and "model" not in d["config"]
+    rf = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in rf, k
+    assert rf["bound"] in ("hbm", "mfma") and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    cb = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in cb, k
+    assert cb["kind"] in ("port", "reference") and cb["value"] > 0 and cb["cores"] >= 1
+    assert d["settle"]["steps"] == 3 and d["step_ms"]["n"] == 4
+
+
 def test_bench_gpus_2_on_one_gpu_over_gloo():
     """`python bench.py --gpus 2` with no launcher starts two ranks itself; here both share the one GPU of the box and
     exchange over gloo (GSR_BENCH_BACKEND=gloo) -- the rehearsal of the view-parallel step (rasterize_view_parallel,
