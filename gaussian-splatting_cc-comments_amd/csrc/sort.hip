@@ -30,7 +30,9 @@
 #ifndef GSR_SORT_ITEMS_LARGE
 #define GSR_SORT_ITEMS_LARGE 16
 #endif
+#ifndef GSR_SORT_ITEMS_SMALL
 #define GSR_SORT_ITEMS_SMALL 4
+#endif
 #define GSR_SORT_SMALL_N (4u << 20)
 // ... and 32 for the largest sorts: re-swept with the LDS ranking, 12 / 16 / 24 / 32 items -> 0.124 / 0.126 / 0.136 / 0.150 ms at
 // R = 9.2M (C3) but 1.30 / 1.17 / 1.12 / 1.07 ms at R = 71M (C5), where the longer digit runs of an 8 192-element block pay
