@@ -277,6 +277,17 @@ def parse_args():
                          "region uses this mode; the other one is timed afterwards and reported under 'alt_exchange'")
     ap.add_argument("--parts", type=int, default=2, help="N > 1: parts of the per-Gaussian backward whose exchange is "
                                                          "started while the next part computes")
+    ap.add_argument("--views-per-rank", type=int, default=1,
+                    help="views every rank renders per step (gradient accumulation over k local views, then ONE exchange of the "
+                         "59 floats/Gaussian through view_parallel.GradientBucket).  Default 1 = BASELINE.json configs[3] (one view "
+                         "per rank and step, exchange pipelined with the per-Gaussian backward); k > 1 shows the amortised case: "
+                         "value counts views, so it stays comparable")
+    ap.add_argument("--collective-timeout-s", type=float, default=180.0,
+                    help="N > 1: timeout of the process group (init and every collective); a rank that waits longer exits non-zero "
+                         "with a message and the launcher stops its siblings")
+    ap.add_argument("--deadline-s", type=float, default=1500.0,
+                    help="N > 1: hard wall-clock limit of a rank; past it the rank prints what it was doing and exits with code 4 "
+                         "(a wrong collective must fail, not hang the node)")
     ap.add_argument("--settle-steps", type=int, default=60,
                     help="steps run before the W warm-up steps (untimed; 0 = off): lets the device reach its steady state for "
                          "this workload, reported as `settle` in the JSON line")
@@ -368,20 +379,48 @@ def main():
             local_rank = local_rank % max(1, torch.cuda.device_count())
         dev = torch.device("cuda", local_rank)
         torch.cuda.set_device(dev)  # before any collective: RCCL binds the communicator to the current device
+    phase = {"now": "start"}
     if world > 1:
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend)
+        import datetime
+        import threading
+
+        def _deadline():
+            print(f"bench.py rank {rank}: --deadline-s {args.deadline_s:.0f} exceeded during '{phase['now']}'; exiting", file=sys.stderr, flush=True)
+            os._exit(4)
+        watchdog = threading.Timer(args.deadline_s, _deadline)
+        watchdog.daemon = True
+        watchdog.start()
+        # a finite timeout for init and every collective: RCCL's watchdog (TORCH_NCCL_ASYNC_ERROR_HANDLING, on by default)
+        # aborts the process when a collective exceeds it, gloo raises -- either way a non-zero exit, never a hang
+        timeout = datetime.timedelta(seconds=args.collective_timeout_s)
+        phase["now"] = "init_process_group"
+        try:
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=dev, timeout=timeout)
+            else:
+                dist.init_process_group(backend, timeout=timeout)
+        except Exception as ex:  # noqa: BLE001
+            print(f"bench.py rank {rank}: process group ({backend}, world {world}) could not be formed within "
+                  f"{args.collective_timeout_s:.0f} s: {ex!r}", file=sys.stderr, flush=True)
+            sys.exit(3)
     try:
-        run_rank(args, rank, world, dev)
-    finally:
-        if world > 1:
-            dist.destroy_process_group()
+        run_rank(args, rank, world, dev, phase)
+    except Exception as ex:  # noqa: BLE001
+        if world > 1:   # a failed or timed-out collective: say so and leave with a code; the launcher stops the other ranks
+            import traceback
+            traceback.print_exc()
+            print(f"bench.py rank {rank}: failed during '{phase['now']}': {ex!r}", file=sys.stderr, flush=True)
+            os._exit(3)   # not sys.exit: destroy_process_group() on a broken communicator can itself block
+        raise
+    if world > 1:
+        phase["now"] = "destroy_process_group"
+        dist.destroy_process_group()
 
 
-def run_rank(args, rank, world, dev):
+def run_rank(args, rank, world, dev, phase=None):
     import view_parallel
+    phase = phase if phase is not None else {}
+    kviews = max(1, int(args.views_per_rank))
     P, W, H, D, mu = gsr_scene.CONFIGS[args.config]
     M = (D + 1) ** 2
     sync = (lambda: None) if args.dry_run else torch.cuda.synchronize
@@ -412,35 +451,49 @@ def run_rank(args, rank, world, dev):
         from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer, _C
         _C.lib()  # fail loudly if the HIP library is missing
         scene = gsr_scene.make_scene(P, mu, D, seed=0)          # replicated parameters
-        cam = gsr_scene.ring_camera(W, H, k=rank, n=max(world, 8)) if world > 1 else gsr_scene.make_camera(W, H)
+        # views of this rank: BASELINE.json configs[3] puts 8 cameras on a ring; rank r renders views r, r + world, ...
+        nviews = world * kviews
+        my_views = view_parallel.shard_views(nviews, rank, world)
+        cams = [gsr_scene.ring_camera(W, H, k=v, n=max(nviews, 8)) for v in my_views] if nviews > 1 else [gsr_scene.make_camera(W, H)]
+        cam = cams[0]
         M = scene.shs.shape[1]
         to = lambda t: t.to(dev)
         params = dict(means3D=to(scene.means3D).requires_grad_(True), shs=to(scene.shs).requires_grad_(True),
                       opacities=to(scene.opacities).requires_grad_(True), scales=to(scene.scales).requires_grad_(True),
                       rotations=to(scene.rotations).requires_grad_(True))
-        settings = GaussianRasterizationSettings(
-            image_height=H, image_width=W, tanfovx=cam.tanfovx, tanfovy=cam.tanfovy, bg=to(scene.bg), scale_modifier=1.0,
-            viewmatrix=to(cam.world_view_transform), projmatrix=to(cam.full_proj_transform), sh_degree=D,
-            campos=to(cam.camera_center), prefiltered=False, debug=False)
-        rasterizer = GaussianRasterizer(settings)
-        g = torch.Generator().manual_seed(1 + rank)
-        dpix = to(torch.randn(3, H, W, generator=g))
+
+        def settings_of(c):
+            return GaussianRasterizationSettings(
+                image_height=H, image_width=W, tanfovx=c.tanfovx, tanfovy=c.tanfovy, bg=to(scene.bg), scale_modifier=1.0,
+                viewmatrix=to(c.world_view_transform), projmatrix=to(c.full_proj_transform), sh_degree=D,
+                campos=to(c.camera_center), prefiltered=False, debug=False)
+        all_settings = [settings_of(c) for c in cams]
+        settings = all_settings[0]
+        rasterizers = [GaussianRasterizer(st) for st in all_settings]
+        rasterizer = rasterizers[0]
+        dpixs = [to(torch.randn(3, H, W, generator=torch.Generator().manual_seed(1 + v))) for v in my_views]
+        dpix = dpixs[0]
         state = {}
-        ex = {m: view_parallel.GradientExchange(P, M, dev, sh_mode=m, parts=args.parts) for m in ("compact", "allreduce")} if world > 1 else {}
+        ex = {m: view_parallel.GradientExchange(P, M, dev, sh_mode=m, parts=args.parts) for m in ("compact", "allreduce")} \
+            if (world > 1 and kviews == 1) else {}
+        bucket = view_parallel.GradientBucket(list(params.values())) if (world > 1 and kviews > 1) else None
 
         def make_step(mode):
             def step():
                 for p in params.values():
                     p.grad = None
-                means2D = torch.zeros_like(params["means3D"], requires_grad=True)  # gaussian_renderer/__init__.py:37
-                if world > 1:
-                    # view-parallel: this rank's view; the backward exchanges the 59 floats/Gaussian of parameter
-                    # gradients part by part (view_parallel.GradientExchange) and returns their sum over the ranks
-                    color, radii = view_parallel.rasterize_view_parallel(params["means3D"], means2D, params["shs"], params["opacities"],
-                                                                         params["scales"], params["rotations"], settings, ex[mode])
-                else:
-                    color, radii = rasterizer(means3D=params["means3D"], means2D=means2D, **{k: v for k, v in params.items() if k != "means3D"})
-                color.backward(dpix)
+                for rast, st, dp in zip(rasterizers, all_settings, dpixs):
+                    means2D = torch.zeros_like(params["means3D"], requires_grad=True)  # gaussian_renderer/__init__.py:37
+                    if world > 1 and kviews == 1:
+                        # view-parallel: this rank's view; the backward exchanges the 59 floats/Gaussian of parameter
+                        # gradients part by part (view_parallel.GradientExchange) and returns their sum over the ranks
+                        color, radii = view_parallel.rasterize_view_parallel(params["means3D"], means2D, params["shs"], params["opacities"],
+                                                                             params["scales"], params["rotations"], st, ex[mode])
+                    else:
+                        color, radii = rast(means3D=params["means3D"], means2D=means2D, **{k: v for k, v in params.items() if k != "means3D"})
+                    color.backward(dp)   # k > 1: autograd accumulates the k local views into .grad
+                if bucket is not None:
+                    bucket.all_reduce()  # ONE flat all-reduce of the 59 floats/Gaussian per step, after the k local views
                 state["color"], state["radii"] = color, radii
             return step
         steps = {m: make_step(m) for m in ("compact", "allreduce")}
@@ -488,11 +541,14 @@ def run_rank(args, rank, world, dev):
     gc.collect()
     gc.disable()
     settle_steps = 0 if args.dry_run else max(0, args.settle_steps)
+    phase["now"] = "settling steps (first collectives of the run)"
     for _ in range(settle_steps):   # a count, the same on every rank (the steps of N > 1 contain collectives)
         step()
     sync()
+    phase["now"] = "warm-up steps"
     for _ in range(args.warmup):
         step()
+    phase["now"] = "timed steps"
     # Timed region: HIP events only around the dominant kernel (every event record drains the queue for
     # ~5 us; bracketing all stages costs ~80 us per step, 4 % of it) plus one event per step boundary.  The full
     # per-kernel table comes from a second, untimed pass below.
@@ -509,7 +565,8 @@ def run_rank(args, rank, world, dev):
         torch.cuda.synchronize()
         ktimes = _C.profile_end(capacity=64 * table_steps)
     alt = None
-    if world > 1:
+    phase["now"] = "per-kernel table / alternative exchange mode"
+    if world > 1 and (args.dry_run or kviews == 1):
         other = "allreduce" if mode == "compact" else "compact"
         for _ in range(max(1, args.warmup)):
             steps[other]()
@@ -520,7 +577,7 @@ def run_rank(args, rank, world, dev):
     if rank != 0:
         return
     ms_per_step = elapsed / args.steps * 1e3
-    out = dict(metric="train iters/sec (fwd+bwd rasterize) @1980x1080, 1M Gaussians", value=round(world * args.steps / elapsed, 3),
+    out = dict(metric="train iters/sec (fwd+bwd rasterize) @1980x1080, 1M Gaussians", value=round(world * kviews * args.steps / elapsed, 3),
                unit="it/s", n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(ms_per_step, 4),
                higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
                step_ms=step_stats(per_step),
@@ -529,11 +586,19 @@ def run_rank(args, rank, world, dev):
                                 "first ~20 steps of a fresh process run up to 7 % slower); --settle-steps 0 disables"))
     if alt is not None:
         out["alt_exchange"] = alt
-    parallelism = (f"view-parallel x{world}, one view per rank, SH gradient exchange: {mode}, backward in {args.parts} parts"
-                   if world > 1 else "single view")
+    if world > 1 and kviews == 1:
+        parallelism = f"view-parallel x{world}, one view per rank, SH gradient exchange: {mode}, backward in {args.parts} parts"
+    elif world > 1:
+        parallelism = (f"view-parallel x{world}, {kviews} views per rank and step (local gradient accumulation), one flat all-reduce of "
+                       "59 floats/Gaussian per step")
+    else:
+        parallelism = "single view" if kviews == 1 else f"{kviews} views per step, gradients accumulated"
+    if kviews > 1:
+        out["views_per_rank"] = kviews
+        out["value_note"] = "value = views (fwd+bwd rasterize iterations) per second over all ranks; one step = views_per_rank views per rank"
     if args.dry_run:
         out.update(data="dry-run: process-group plumbing and gradient exchange only, NO rasterizer (not a measurement)",
-                   config=dict(workload=f"{args.config}: exchange buffers of {P} Gaussians", P=P, views_per_step=world, parallelism=parallelism))
+                   config=dict(workload=f"{args.config}: exchange buffers of {P} Gaussians", P=P, views_per_step=world * kviews, parallelism=parallelism))
         print(json.dumps(out), flush=True)
         return
 
@@ -592,7 +657,7 @@ def run_rank(args, rank, world, dev):
                         step_GBps=round(step_bytes / (ms_per_step * 1e-3) / 1e9, 1),
                         step_frac=round(step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
     out.update(config=dict(workload=f"{args.config}: {P} Gaussians, SH deg {D}, {W}x{H}, mu={mu}, seed 0",
-                           P=P, V=V, R=R, R_staged_fwd=Rp, views_per_step=world, parallelism=parallelism),
+                           P=P, V=V, R=R, R_staged_fwd=Rp, views_per_step=world * kviews, parallelism=parallelism),
                roofline=roofline, kernels=kern,
                kernels_note=f"per-kernel ms: HIP events on the launch stream; '{DOMINANT_STAGE}' over the timed region, the "
                             f"others over {table_steps} extra untimed steps (bracketing every stage inside the timed region "
@@ -605,7 +670,7 @@ def run_rank(args, rank, world, dev):
             for p in params.values():
                 p.grad = None
             out["train_iteration"] = bench_train_step(scene, settings, D, dev)
-    if world == 1 and not args.no_cpu_baseline:
+    if world == 1 and kviews == 1 and not args.no_cpu_baseline:
         import numpy as np
         cb, o = cpu_baseline(scene, cam, D)
         out["cpu_baseline"] = cb

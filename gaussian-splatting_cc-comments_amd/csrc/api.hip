@@ -36,7 +36,7 @@ int gsr_stage_done(hipStream_t s, int debug, const char* stage)
 {
 	hipError_t e = hipGetLastError();
 	if (e != hipSuccess) return gsr_fail(GSR_ERR_HIP, "launch of %s failed: %s", stage, hipGetErrorString(e));
-	if (debug) {  // CHECK_CUDA semantics, auxiliary.h:177-184
+	if (debug & GSR_DEBUG_SYNC) {  // CHECK_CUDA semantics, auxiliary.h:177-184
 		e = hipStreamSynchronize(s);
 		if (e != hipSuccess) return gsr_fail(GSR_ERR_HIP, "[HIP ERROR] in stage %s: %s", stage, hipGetErrorString(e));
 	}
@@ -44,7 +44,7 @@ int gsr_stage_done(hipStream_t s, int debug, const char* stage)
 }
 
 extern "C" const char* gsr_last_error(void) { return g_err; }
-extern "C" const char* gsr_version(void) { return "gsr-hip gfx950 r2"; }
+extern "C" const char* gsr_version(void) { return "gsr-hip gfx950 r3"; }
 
 // ---- per-kernel event profiling ----------------------------------------------------------------
 // One recorder per stream that asked for it (gsr_profile_begin(stream)).  A stage looks its stream up; with no
@@ -290,6 +290,59 @@ extern "C" uint32_t gsr_get_higher_msb(uint32_t n)
 
 static bool aligned16(const void* p) { return ((uintptr_t)p & 15u) == 0; }
 
+// ---- per-thread helper resources -----------------------------------------------------------------
+// One helper stream (+ fork / join events) and one pinned landing buffer (+ its event) per host thread and device, created
+// on first use by gsr_forward_preprocess*.  They are the only things the library keeps between calls; a thread that is
+// done with the library returns them with gsr_thread_release().
+struct GsrThreadDevice {
+	hipStream_t aux_stream = nullptr;
+	hipEvent_t aux_fork = nullptr, aux_join = nullptr;
+	uint32_t* status_host = nullptr;
+	hipEvent_t status_event = nullptr;
+};
+struct GsrThreadState { GsrThreadDevice dev[GSR_MAX_DEVICES]; };
+static thread_local GsrThreadState g_thread;
+
+extern "C" int gsr_thread_release(void)
+{
+	g_err[0] = 0;
+	int rc = GSR_OK;
+	for (int d = 0; d < GSR_MAX_DEVICES; d++) {
+		GsrThreadDevice& t = g_thread.dev[d];
+		// the helper stream's work was joined into the caller's stream by every call; draining it here covers a caller
+		// that releases while its own stream still runs
+		if (t.aux_stream) { (void)hipStreamSynchronize(t.aux_stream); if (hipStreamDestroy(t.aux_stream) != hipSuccess) rc = GSR_ERR_HIP; }
+		if (t.aux_fork && hipEventDestroy(t.aux_fork) != hipSuccess) rc = GSR_ERR_HIP;
+		if (t.aux_join && hipEventDestroy(t.aux_join) != hipSuccess) rc = GSR_ERR_HIP;
+		if (t.status_event && hipEventDestroy(t.status_event) != hipSuccess) rc = GSR_ERR_HIP;
+		if (t.status_host && hipHostFree(t.status_host) != hipSuccess) rc = GSR_ERR_HIP;
+		t = GsrThreadDevice();
+	}
+	if (rc) { (void)hipGetLastError(); return gsr_fail(rc, "gsr_thread_release: a HIP resource could not be freed"); }
+	return GSR_OK;
+}
+
+// Makes `stream` wait for the helper stream's join event when the scope ends, unless now() already did.
+struct GsrJoinOnExit {
+	hipStream_t s;
+	hipEvent_t ev = nullptr;
+	explicit GsrJoinOnExit(hipStream_t st) : s(st) {}
+	void arm(hipEvent_t e) { ev = e; }
+	int now()
+	{
+		if (!ev) return GSR_OK;
+		hipEvent_t e = ev;
+		ev = nullptr;
+		if (hipStreamWaitEvent(s, e, 0) == hipSuccess) return GSR_OK;
+		(void)hipEventSynchronize(e);  // the stream could not be made to wait: the host waits instead
+		return gsr_fail(GSR_ERR_HIP, "hipStreamWaitEvent(join) failed");
+	}
+	~GsrJoinOnExit()
+	{
+		if (ev && hipStreamWaitEvent(s, ev, 0) != hipSuccess) (void)hipEventSynchronize(ev);
+	}
+};
+
 // ---- forward, stage 1 --------------------------------------------------------------------------
 static int gsr_forward_preprocess_impl(int P, int D, int M, int width, int height, const float* means3D,
                                        const float* shs, const float* shs_rest, int leaf, const float* colors_precomp,
@@ -337,34 +390,40 @@ static int gsr_forward_preprocess_impl(int P, int D, int M, int width, int heigh
 	if ((rc = gsr_check_hip(hipGetDevice(&device), "hipGetDevice"))) return rc;
 	if (device < 0 || device >= GSR_MAX_DEVICES) return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "device index %d not supported", device);
 	// The SH colours are needed by nothing before the blend: their kernel runs on a helper stream (one per host thread and
-	// device, created on first use) beside the geometry kernel and the depth sort, whose launches are short and leave most
-	// of the chip idle, and is joined before this call's last kernel.  In line instead when every stage is being timed, in
-	// debug mode (a device sync follows every stage) and with GSR_SERIAL=1.
-	static thread_local hipStream_t aux_stream_of[GSR_MAX_DEVICES] = {nullptr};
-	static thread_local hipEvent_t aux_fork_of[GSR_MAX_DEVICES] = {nullptr}, aux_join_of[GSR_MAX_DEVICES] = {nullptr};
+	// device, created on first use, freed by gsr_thread_release()) beside the geometry kernel and the depth sort, whose
+	// launches are short and leave most of the chip idle, and is joined before this call's last kernel.  In line instead
+	// when every stage is being timed, with GSR_DEBUG_SYNC (a device sync follows every stage) and with GSR_DEBUG_SERIAL.
+	GsrThreadDevice& td = g_thread.dev[device];
 	const bool color = gsr_preprocess_needs_color(a);
-	bool beside = color && !debug && !gsr_prof_records_all(s);
-	if (beside) {
-		const char* e = getenv("GSR_SERIAL");
-		if (e && e[0] == '1') beside = false;
-	}
-	if (beside && !aux_stream_of[device]) {
+	bool beside = color && !(debug & (GSR_DEBUG_SYNC | GSR_DEBUG_SERIAL)) && !gsr_prof_records_all(s);
+	if (beside && !td.aux_stream) {
 		hipStream_t st = nullptr;
 		hipEvent_t f = nullptr, j = nullptr;
 		if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&f, hipEventDisableTiming) == hipSuccess &&
 		    hipEventCreateWithFlags(&j, hipEventDisableTiming) == hipSuccess) {
-			aux_stream_of[device] = st; aux_fork_of[device] = f; aux_join_of[device] = j;
+			td.aux_stream = st; td.aux_fork = f; td.aux_join = j;
 		} else {
 			(void)hipGetLastError();
+			if (st) (void)hipStreamDestroy(st);
+			if (f) (void)hipEventDestroy(f);
+			if (j) (void)hipEventDestroy(j);
 			beside = false;  // no helper stream: the colour kernel runs in line
 		}
 	}
+	// From the fork on, EVERY return -- the error returns too -- first makes the caller's stream wait for the colour kernel:
+	// the caller is free to release or reuse `geometry` on `stream` the moment this call returns (include/gsr.h, stream
+	// contract), and the helper stream may still be writing rgb / clamp bits / sh_ddir into it.
+	GsrJoinOnExit join(s);
 	if (beside) {
 		// fork: the helper stream starts where the caller's stream stands now (its inputs are ready there)
-		if ((rc = gsr_check_hip(hipEventRecord(aux_fork_of[device], s), "hipEventRecord(fork)"))) return rc;
-		if ((rc = gsr_check_hip(hipStreamWaitEvent(aux_stream_of[device], aux_fork_of[device], 0), "hipStreamWaitEvent(fork)"))) return rc;
-		gsr_launch_preprocess_color(a, aux_stream_of[device]);
-		if ((rc = gsr_check_hip(hipEventRecord(aux_join_of[device], aux_stream_of[device]), "hipEventRecord(join)"))) return rc;
+		if ((rc = gsr_check_hip(hipEventRecord(td.aux_fork, s), "hipEventRecord(fork)"))) return rc;
+		if ((rc = gsr_check_hip(hipStreamWaitEvent(td.aux_stream, td.aux_fork, 0), "hipStreamWaitEvent(fork)"))) return rc;
+		gsr_launch_preprocess_color(a, td.aux_stream);
+		if (hipEventRecord(td.aux_join, td.aux_stream) != hipSuccess) {
+			(void)hipStreamSynchronize(td.aux_stream);  // no event to wait for: wait on the host instead, then report
+			return gsr_fail(GSR_ERR_HIP, "hipEventRecord(join) failed");
+		}
+		join.arm(td.aux_join);
 	}
 	if ((rc = gsr_check_hip(hipMemsetAsync(a.g.status, 0, GSR_STATUS_WORDS * 4, s), "hipMemsetAsync(status)"))) return rc;
 	{
@@ -381,14 +440,14 @@ static int gsr_forward_preprocess_impl(int P, int D, int M, int width, int heigh
 	// read num_rendered back; the per-Gaussian half of the sort is enqueued behind the copy and keeps
 	// the GPU busy while the host waits on the event, allocates the binning buffer and launches stage 2
 	// pinned landing buffer + event, created once per (thread, device) and reused
-	static thread_local uint32_t* status_host_of[GSR_MAX_DEVICES] = {nullptr};
-	static thread_local hipEvent_t event_of[GSR_MAX_DEVICES] = {nullptr};
-	if (!status_host_of[device]) {
-		if ((rc = gsr_check_hip(hipHostMalloc((void**)&status_host_of[device], GSR_STATUS_WORDS * 4, hipHostMallocDefault), "hipHostMalloc"))) return rc;
-		if ((rc = gsr_check_hip(hipEventCreateWithFlags(&event_of[device], hipEventDisableTiming), "hipEventCreate"))) return rc;
+	if (!td.status_host) {
+		if ((rc = gsr_check_hip(hipHostMalloc((void**)&td.status_host, GSR_STATUS_WORDS * 4, hipHostMallocDefault), "hipHostMalloc"))) return rc;
 	}
-	uint32_t* status_host = status_host_of[device];
-	hipEvent_t ev = event_of[device];
+	if (!td.status_event) {
+		if ((rc = gsr_check_hip(hipEventCreateWithFlags(&td.status_event, hipEventDisableTiming), "hipEventCreate"))) return rc;
+	}
+	uint32_t* status_host = td.status_host;
+	hipEvent_t ev = td.status_event;
 	if ((rc = gsr_check_hip(hipMemcpyAsync(status_host, a.g.status, GSR_STATUS_WORDS * 4, hipMemcpyDeviceToHost, s), "hipMemcpyAsync(num_rendered)"))) return rc;
 	if ((rc = gsr_check_hip(hipEventRecord(ev, s), "hipEventRecord"))) return rc;
 	// The depth sort orders key - min (keys = float bits of the view-space depth; min / max: partial maxima in the status
@@ -404,10 +463,8 @@ static int gsr_forward_preprocess_impl(int P, int D, int M, int width, int heigh
 	}
 	if ((rc = gsr_stage_done(s, debug, "depth_sort"))) return rc;
 	if ((rc = gsr_check_hip(hipEventSynchronize(ev), "hipEventSynchronize(num_rendered)"))) return rc;
-	if (status_host[0] & 1u) {
-		if (beside) (void)hipStreamWaitEvent(s, aux_join_of[device], 0);
+	if (status_host[0] & 1u)  // (the join guard makes `stream` wait for the colour kernel first)
 		return gsr_fail(GSR_ERR_PREFILTERED, "Point is filtered although prefiltered is set. This shouldn't happen!");
-	}
 	int64_t total = 0;
 	uint32_t negmin = 0, kmax = 0;
 	for (int k = 0; k < GSR_COUNT_PARTS; k++) {
@@ -420,7 +477,7 @@ static int gsr_forward_preprocess_impl(int P, int D, int M, int width, int heigh
 	const uint32_t culled_value = kmax >= kmin ? (kmax - kmin) + 1u : 0u;   // largest biased key (what culled Gaussians sort as)
 	const int fourth = (culled_value >> 24) != 0u || (kmax >= kmin && kmax - kmin == 0xFFFFFFFFu);
 	// join: everything the caller enqueues after this call comes after the colour kernel too
-	if (beside && (rc = gsr_check_hip(hipStreamWaitEvent(s, aux_join_of[device], 0), "hipStreamWaitEvent(join)"))) return rc;
+	if ((rc = join.now())) return rc;
 	if (fourth) {
 		GsrProfScope p(s, "depth_sort");
 		gsr_radix_sort_passes(a.g.depth_keys, a.g.perm, a.g.depth_keys_alt, a.g.perm_alt, (size_t)P, 32, 4, 3, 1, a.g.sort_table, bias, s);
@@ -507,7 +564,7 @@ extern "C" int gsr_forward_render(int P, int64_t R, int width, int height, const
 	if ((rc = gsr_stage_done(s, debug, "tile_order"))) return rc;
 	{
 		GsrProfScope p(s, "render_forward");
-				gsr_launch_render_forward(width, height, im, b.point_list, g.splat, background, out_color, R > 0, s);
+				gsr_launch_render_forward(width, height, im, b.point_list, g.splat, background, out_color, R > 0, !(debug & GSR_DEBUG_NO_CULL), s);
 	}
 	return gsr_stage_done(s, debug, "render_forward");
 }
@@ -569,7 +626,7 @@ extern "C" int gsr_backward_blend(const gsr_backward_args* args)
 	{
 		GsrProfScope p(s, "render_backward");
 		gsr_launch_render_backward(a.width, a.height, im, b.point_list, g.splat, g.slot_base, a.background, a.dL_dpix,
-		                           (GsrGradSlot*)a.scratch, (uint8_t*)b.tile_keys_alt, s);
+		                           (GsrGradSlot*)a.scratch, (uint8_t*)b.tile_keys_alt, !(a.debug & GSR_DEBUG_NO_CULL), s);
 	}
 	return gsr_stage_done(s, a.debug, "render_backward");
 }

@@ -123,12 +123,12 @@ void gsr_radix_sort_u32(uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v1, 
 
 // render_forward.hip
 void gsr_launch_render_forward(int W, int H, GsrImage img, const uint32_t* point_list, const GsrSplat* splat,
-                               const float* bg, float* out_color, bool ordered, hipStream_t s);
+                               const float* bg, float* out_color, bool ordered, bool cull, hipStream_t s);
 
 // render_backward.hip
 void gsr_launch_render_backward(int W, int H, GsrImage img, const uint32_t* point_list, const GsrSplat* splat,
                                 const uint32_t* slot_base, const float* bg, const float* dL_dpix, GsrGradSlot* slots,
-                                uint8_t* slot_valid, hipStream_t s);
+                                uint8_t* slot_valid, bool cull, hipStream_t s);
 
 // gaussian_backward.hip
 struct GsrGaussianBackwardArgs {

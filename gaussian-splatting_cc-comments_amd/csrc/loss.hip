@@ -21,6 +21,9 @@
 #define GSR_LOSS_TX 64
 // tile height: 16 / 32 rows -> 0.151 / 0.137 ms for the 1980x1080 loss (fwd + bwd), 0.59 / 0.52 ms at 3840x2160: the taller tile
 // re-reads less halo (42 / 32 rows instead of 26 / 16) and its 512-thread workgroups fill the SIMDs better
+// 32-row tiles need ~79 KB (forward) / ~70 KB (backward) of static LDS per workgroup: more than the 64 KB of every gfx9
+// part except gfx950 (160 KB per CU, two workgroups resident).  This library is built for gfx950 only (csrc/Makefile);
+// -DGSR_LOSS_TY=16 is the variant that fits 64 KB, should the ARCH override of the Makefile ever be used.
 #ifndef GSR_LOSS_TY
 #define GSR_LOSS_TY 32
 #endif
@@ -99,6 +102,7 @@ __global__ void __launch_bounds__(GSR_LOSS_THREADS) gsr_ssim_forward_kernel(int 
 	__shared__ __attribute__((aligned(16))) float sx[GSR_LOSS_HY * GSR_LOSS_HXS], sy[GSR_LOSS_HY * GSR_LOSS_HXS];
 	__shared__ __attribute__((aligned(16))) float tmp[5][GSR_LOSS_HY * GSR_LOSS_TX];
 	__shared__ float2 wsum[GSR_LOSS_THREADS / 64];
+	static_assert(sizeof(sx) + sizeof(sy) + sizeof(tmp) <= 80 * 1024, "two workgroups per CU must fit gfx950's 160 KB of LDS");
 	const int c = blockIdx.z;
 	const size_t plane = (size_t)H * W;
 	const int x0 = blockIdx.x * GSR_LOSS_TX - GSR_LOSS_R, y0 = blockIdx.y * GSR_LOSS_TY - GSR_LOSS_R;

@@ -242,12 +242,12 @@ __global__ void __launch_bounds__(64 * GSR_WAVES_PER_WG) __attribute__((amdgpu_w
 
 void gsr_launch_render_backward(int W, int H, GsrImage img, const uint32_t* point_list, const GsrSplat* splat,
                                 const uint32_t* slot_base, const float* bg, const float* dL_dpix, GsrGradSlot* slots,
-                                uint8_t* slot_valid, hipStream_t s)
+                                uint8_t* slot_valid, bool cull, hipStream_t s)
 {
 	const int gx = gsr_grid_x(W), gy = gsr_grid_y(H);
 	const int ntiles = gx * gy;
 	const int nwg = (ntiles + GSR_WAVES_PER_WG - 1) / GSR_WAVES_PER_WG;
 	hipLaunchKernelGGL(gsr_render_backward_wave_kernel, dim3(nwg), dim3(64 * GSR_WAVES_PER_WG), 0, s, W, H, gx, ntiles,
 	                   img.ranges, point_list, splat, slot_base, bg, img.final_T, img.n_contrib, img.tile_max_contrib,
-	                   img.tile_order, dL_dpix, slots, slot_valid, gsr_culling_enabled());
+	                   img.tile_order, dL_dpix, slots, slot_valid, cull ? 1 : 0);
 }

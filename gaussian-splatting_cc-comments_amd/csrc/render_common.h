@@ -8,14 +8,9 @@
 #pragma once
 #include "gsr_internal.h"
 
-#include <stdlib.h>
-// Diagnostic knob: GSR_NO_CULL=1 disables the exact-result-preserving culling (every instance of
-// the reference's tile list is evaluated on every band), to bisect a suspected culling error.
-static inline int gsr_culling_enabled()
-{
-	const char* e = getenv("GSR_NO_CULL");  // read at every launch: a test can switch it inside one process
-	return (e && e[0] == '1') ? 0 : 1;
-}
+// The blend kernels take `cull` as a launch argument: 0 (GSR_DEBUG_NO_CULL in the `debug` mask of the C ABI, include/gsr.h)
+// disables the exact-result-preserving culling below -- every instance of the reference's tile list is evaluated on every
+// band -- to bisect a suspected culling error.  Nothing is read from the environment.
 
 #define GSR_WAVES_PER_WG 1
 #define GSR_PIX_PER_LANE 4

@@ -158,12 +158,12 @@ __global__ void __launch_bounds__(64 * GSR_WAVES_PER_WG) gsr_render_forward_wave
 }
 
 void gsr_launch_render_forward(int W, int H, GsrImage img, const uint32_t* point_list, const GsrSplat* splat,
-                               const float* bg, float* out_color, bool ordered, hipStream_t s)
+                               const float* bg, float* out_color, bool ordered, bool cull, hipStream_t s)
 {
 	const int gx = gsr_grid_x(W), gy = gsr_grid_y(H);
 	const int ntiles = gx * gy;
 	const int nwg = (ntiles + GSR_WAVES_PER_WG - 1) / GSR_WAVES_PER_WG;
 	hipLaunchKernelGGL(gsr_render_forward_wave_kernel, dim3(nwg), dim3(64 * GSR_WAVES_PER_WG), 0, s, W, H, gx, ntiles,
 	                   img.ranges, point_list, splat, bg, img.final_T, img.n_contrib, img.tile_max_contrib,
-	                   ordered ? img.tile_order : nullptr, out_color, gsr_culling_enabled());
+	                   ordered ? img.tile_order : nullptr, out_color, cull ? 1 : 0);
 }

@@ -15,7 +15,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# GSR_HIP_LIBRARY: another build of the same C ABI (e.g. the diagnostic build of tools/tile_timing.py)
+# GSR_HIP_LIBRARY: another build of the same C ABI (e.g. the diagnostic build of tools/tile_clock.py)
 _LIB_PATH = os.environ.get("GSR_HIP_LIBRARY") or os.path.join(os.path.dirname(_HERE), "libgsr_hip.so")
 _lib = None
 
@@ -55,6 +55,15 @@ class BackwardArgs(ctypes.Structure):
                                     "dL_dopacity", "dL_dcolor", "dL_dmean3D", "dL_dcov3D", "dL_dsh", "dL_dsh_rest", "dL_dscale",
                                     "dL_drot", "stat_xyz_gradient_accum", "stat_denom", "stat_max_radii2D", "stream")] +
                 [("debug", _i)])
+
+
+# bits of the C ABI's `debug` mask (include/gsr.h GSR_DEBUG_*).  The reference's bool `debug` is DEBUG_SYNC; tests pass the
+# diagnostic bits as an int in the same argument, per call -- nothing is read from the environment.
+DEBUG_SYNC, DEBUG_NO_CULL, DEBUG_SERIAL = 1, 2, 4
+
+
+def _dbg(debug):
+    return int(debug) if (isinstance(debug, int) and not isinstance(debug, bool)) else int(bool(debug))
 
 
 def library_path():
@@ -101,6 +110,8 @@ def lib():
     L.gsr_backward_blend.argtypes = [ctypes.POINTER(BackwardArgs)]
     L.gsr_backward_gaussians.restype = _i
     L.gsr_backward_gaussians.argtypes = [ctypes.POINTER(BackwardArgs), _i, _i, _i]
+    L.gsr_thread_release.restype = _i
+    L.gsr_thread_release.argtypes = []
     L.gsr_profile_begin.restype = _i
     L.gsr_profile_begin.argtypes = [_vp]
     L.gsr_profile_begin_only.restype = _i
@@ -173,11 +184,11 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
                                         _ptr(scales), float(scale_modifier), _ptr(rotations), _ptr(cov3D_precomp),
                                         _ptr(viewmatrix), _ptr(projmatrix), _ptr(campos), float(tan_fovx),
                                         float(tan_fovy), int(bool(prefiltered)), _ptr(radii), _ptr(geom),
-                                        ctypes.byref(R), stream, int(bool(debug))))
+                                        ctypes.byref(R), stream, _dbg(debug)))
         R = int(R.value)
         binning = torch.empty((L.gsr_binning_bytes(P, R, W, H),), **byte)
         _check(L.gsr_forward_render(P, R, W, H, _ptr(background), _ptr(radii), _ptr(geom), _ptr(binning), _ptr(img),
-                                    _ptr(out_color), stream, int(bool(debug))))
+                                    _ptr(out_color), stream, _dbg(debug)))
     return R, out_color, radii, geom, binning, img
 
 
@@ -231,7 +242,7 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
                                       _ptr(radii), _ptr(geomBuffer), _ptr(binningBuffer), _ptr(imageBuffer), _ptr(scratch),
                                       _ptr(dL_dout_color), _ptr(dL_dmeans2D), _ptr(dL_dconic), _ptr(dL_dopacity),
                                       _ptr(dL_dcolors), _ptr(dL_dmeans3D), _ptr(dL_dcov3D), _ptr(dL_dsh), _ptr(dL_dscales),
-                                      _ptr(dL_drotations), _stream(dev), int(bool(debug))))
+                                      _ptr(dL_drotations), _stream(dev), _dbg(debug)))
             else:
                 a = backward_args(P=P, D=int(degree), M=M, R=int(R), W=W, H=H, leaf=0, background=background, means3D=means3D,
                                   shs=sh, colors_precomp=colors, scales=scales, scale_modifier=scale_modifier,
@@ -267,7 +278,7 @@ def backward_args(*, P, D, M, R, W, H, leaf, background, means3D, shs, scales, s
         setattr(a, name, _ptr(t))
     a.scale_modifier, a.tan_fovx, a.tan_fovy = float(scale_modifier), float(tan_fovx), float(tan_fovy)
     a.stream = _stream(device)
-    a.debug = int(bool(debug))
+    a.debug = _dbg(debug)
     return a
 
 
@@ -339,6 +350,11 @@ def mark_visible(means3D, viewmatrix, projmatrix):
         with torch.cuda.device(dev):
             _check(L.gsr_mark_visible(P, _ptr(means3D), _ptr(viewmatrix), _ptr(projmatrix), _ptr(present), _stream(dev)))
     return present
+
+
+def thread_release():
+    """include/gsr.h gsr_thread_release: frees the calling thread's helper stream, events and pinned buffer."""
+    _check(lib().gsr_thread_release())
 
 
 # ---- introspection helpers (tests / bench; not part of the reference surface) ----------------------

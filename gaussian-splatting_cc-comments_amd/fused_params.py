@@ -84,11 +84,11 @@ def leaf_forward(xyz, features_dc, features_rest, opacity, scaling, rotation, ra
                 P, int(st.sh_degree), M, W, H, xyz.data_ptr(), features_dc.data_ptr(), _C._ptr(features_rest),
                 opacity.data_ptr(), scaling.data_ptr(), float(st.scale_modifier), rotation.data_ptr(), view.data_ptr(),
                 proj.data_ptr(), campos.data_ptr(), float(st.tanfovx), float(st.tanfovy), int(bool(st.prefiltered)),
-                radii.data_ptr(), geom.data_ptr(), ctypes.byref(Rv), stream, int(bool(st.debug))))
+                radii.data_ptr(), geom.data_ptr(), ctypes.byref(Rv), stream, _C._dbg(st.debug)))
             R = int(Rv.value)
             binning = torch.empty((L.gsr_binning_bytes(P, R, W, H),), **byte)
             _C._check(L.gsr_forward_render(P, R, W, H, bg.data_ptr(), radii.data_ptr(), geom.data_ptr(), _C._ptr(binning),
-                                           img.data_ptr(), color.data_ptr(), stream, int(bool(st.debug))))
+                                           img.data_ptr(), color.data_ptr(), stream, _C._dbg(st.debug)))
     return R, color, radii, geom, binning, img, M, (xyz, features_dc, features_rest, scaling, rotation)
 
 

@@ -95,16 +95,18 @@ class GradientExchange:
     part's kernel computes); finish() waits and returns the summed gradients as whole-scene tensors."""
 
     def __init__(self, P: int, M: int, device, group: Optional[dist.ProcessGroup] = None, sh_mode: str = "compact",
-                 parts: int = 2, leaf: bool = False):
+                 parts: int = 2):
         if sh_mode not in ("compact", "allreduce"):
             raise ValueError(f"sh_mode {sh_mode!r}")
-        self.P, self.M, self.group, self.sh_mode, self.leaf = int(P), int(M), group, sh_mode, bool(leaf)
+        if int(P) < 0:
+            raise ValueError(f"P = {P}")
+        self.P, self.M, self.group, self.sh_mode = int(P), int(M), group, sh_mode
         self.world = _world(group)
         self.device = torch.device(device)
         nparts = max(1, min(int(parts), max(1, self.P // 256)))
         step = -(-self.P // nparts)
-        step = -(-step // 256) * 256
-        self.ranges = [(f, min(step, self.P - f)) for f in range(0, max(self.P, 1), step) if self.P - f > 0] or [(0, 0)]
+        step = max(256, -(-step // 256) * 256)   # P == 0 (an empty scene, rasterize_points.cu:94) gives the one empty part (0, 0)
+        self.ranges = [(f, min(step, self.P - f)) for f in range(0, self.P, step)] or [(0, 0)]
         f32 = dict(dtype=torch.float32, device=self.device)
         self.bucket = [torch.zeros(11 * c, **f32) for _, c in self.ranges]
         self.rgb = [torch.zeros((c + 1, 3), **f32) for _, c in self.ranges] if sh_mode == "compact" else None
@@ -208,8 +210,8 @@ class _RasterizeViewParallel(torch.autograd.Function):
         if grad_color is None:
             grad_color = torch.zeros((3, int(st.image_height), int(st.image_width)), dtype=torch.float32, device=dev)
         P, M = int(means3D.size(0)), int(shs.size(1))
-        if (P, M) != (ex.P, ex.M) or ex.leaf:
-            raise RuntimeError(f"GradientExchange was built for P={ex.P}, M={ex.M}, leaf={ex.leaf}; got P={P}, M={M}")
+        if (P, M) != (ex.P, ex.M):
+            raise RuntimeError(f"GradientExchange was built for P={ex.P}, M={ex.M}; got P={P}, M={M}")
         with torch.cuda.device(dev):
             d_means2D = torch.empty((P, 3), dtype=torch.float32, device=dev)
             ex.begin_step()
@@ -309,7 +311,9 @@ class DensificationStats:
         vis = radii > 0
         self._local_sum[0] += torch.norm(viewspace_grad[:, :2], dim=-1) * vis
         self._local_sum[1] += vis.to(self._local_sum.dtype)
-        self._local_max = torch.max(self._local_max, torch.where(vis, radii, torch.zeros_like(radii)).to(self._local_max.dtype))
+        # in place: kernel_tensors() hands out views of these accumulators, and rasterizer objects / autograd contexts keep
+        # them across steps -- a rebound tensor would orphan what the kernel epilogue writes afterwards
+        torch.maximum(self._local_max, torch.where(vis, radii, torch.zeros_like(radii)).to(self._local_max.dtype), out=self._local_max)
 
     @torch.no_grad()
     def sync(self, group: Optional[dist.ProcessGroup] = None):

@@ -12,8 +12,10 @@
  * scales / rotations / cov3D_precomp exactly where the reference passes an empty tensor.
  *
  * Return value: 0 on success, otherwise a negative gsr_status; gsr_last_error() returns a
- * thread-local message for the last failure.  With debug != 0 every stage is followed by a
- * stream synchronise + error check, like CHECK_CUDA (cuda_rasterizer/auxiliary.h:177-184).
+ * thread-local message for the last failure.  `debug` is a bit mask (GSR_DEBUG_*): the reference's
+ * bool `debug` is GSR_DEBUG_SYNC = 1 -- every stage is followed by a stream synchronise + error
+ * check, like CHECK_CUDA (cuda_rasterizer/auxiliary.h:177-184); the other bits are diagnostics that
+ * travel with the call (the library reads nothing from the environment and keeps no switches).
  *
  * The three state buffers (geometry / binning / image) are opaque byte blobs that only travel
  * forward -> backward, like the reference's geomBuffer / binningBuffer / imgBuffer
@@ -38,11 +40,23 @@ typedef enum {
 	GSR_ERR_BUFFER_TOO_SMALL = -4
 } gsr_status;
 
+/* bits of the `debug` argument of every entry point that has one (and of gsr_backward_args.debug) */
+#define GSR_DEBUG_SYNC    1  /* the reference's debug = true: synchronise + check after every stage */
+#define GSR_DEBUG_NO_CULL 2  /* blend kernels evaluate every (instance, pixel band) pair of a tile's list, like the reference,
+                                instead of skipping the pairs proven to contribute nothing: bisects a suspected culling error */
+#define GSR_DEBUG_SERIAL  4  /* gsr_forward_preprocess*: the SH colour kernel runs in line on `stream`, not on the helper stream */
+
 /* Message of the last failing call on this thread ("" if none). */
 const char* gsr_last_error(void);
 
 /* Library / build identification, e.g. "gsr-hip gfx950 r1". */
 const char* gsr_version(void);
+
+/* Frees what the calling host thread's earlier calls created and kept for reuse: per device one helper stream with
+ * its two events, one pinned 784-byte landing buffer for the instance count and its event (all created on first use
+ * by gsr_forward_preprocess*).  Optional -- a later call simply creates them again; meant for worker threads that
+ * end, and for leak checkers.  Call it when none of this thread's library calls is still executing. */
+int gsr_thread_release(void);
 
 /* ---- buffer sizing (replaces required<GeometryState/ImageState/BinningState>(),
  *      cuda_rasterizer/rasterizer_impl.h:65-73 and the resize callbacks rasterize_points.cu:28-36) */
@@ -107,8 +121,9 @@ int gsr_binning_layout_of(int P, int64_t num_rendered, int width, int height, gs
  * Streams: all work is ordered after what `stream` holds on entry and is complete, in `stream`'s order, for whatever
  * the caller enqueues after the call.  Inside the call the SH colour kernel runs on a helper stream of the library (one
  * per host thread and device, non-blocking, forked from and joined into `stream` with events) beside the geometry
- * kernel and the depth sort; GSR_SERIAL=1 in the environment, debug != 0 and an all-stages gsr_profile_begin() keep
- * it on `stream`.
+ * kernel and the depth sort; GSR_DEBUG_SERIAL or GSR_DEBUG_SYNC in `debug` and an all-stages gsr_profile_begin() keep
+ * it on `stream`.  Every return of the call, error returns included, leaves `stream` ordered after the helper stream's
+ * work, so `geometry` may be released or reused on `stream` as soon as the call has returned.
  */
 int gsr_forward_preprocess(
 	int P, int D, int M,

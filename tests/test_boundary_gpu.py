@@ -23,18 +23,19 @@ def _need_gpu():
         pytest.skip("no GPU")
 
 
-def _direct(scene, cam, D, dpix, dev, **kw):
-    """forward + backward through the binding (no autograd): every tensor the reference's extension returns."""
+def _direct(scene, cam, D, dpix, dev, debug=0, **kw):
+    """forward + backward through the binding (no autograd): every tensor the reference's extension returns.
+    debug: the C ABI's mask (include/gsr.h GSR_DEBUG_*), e.g. _C.DEBUG_NO_CULL."""
     from diff_gaussian_rasterization import _C
     st = util.hip_settings(scene, cam, D, dev)
     e = torch.empty(0, device=dev)
     t = {k: getattr(scene, k).to(dev) for k in ("means3D", "shs", "opacities", "scales", "rotations")}
     R, color, radii, geom, binning, img = _C.rasterize_gaussians(
         st.bg, t["means3D"], e, t["opacities"], t["scales"], t["rotations"], 1.0, e, st.viewmatrix, st.projmatrix, st.tanfovx,
-        st.tanfovy, st.image_height, st.image_width, t["shs"], D, st.campos, False, False)
+        st.tanfovy, st.image_height, st.image_width, t["shs"], D, st.campos, False, debug)
     grads = _C.rasterize_gaussians_backward(
         st.bg, t["means3D"], radii, e, t["scales"], t["rotations"], 1.0, e, st.viewmatrix, st.projmatrix, st.tanfovx, st.tanfovy,
-        dpix, t["shs"], D, st.campos, geom, R, binning, img, False, **kw)
+        dpix, t["shs"], D, st.campos, geom, R, binning, img, debug, **kw)
     return (color, radii) + tuple(grads)
 
 
@@ -154,15 +155,17 @@ def test_radii_may_be_null_like_the_reference_default():
         assert torch.equal(got, want)
 
 
-@pytest.mark.parametrize("case", ["fuzz", "C2"])
+@pytest.mark.parametrize("case", ["fuzz", "C2", "C3"])
 def test_band_culling_changes_nothing(case):
     """The staging lanes drop (instance, 16x4-pixel band) pairs that cannot reach alpha = 1/255 (render_common.h
-    gsr_tile_band_mask).  GSR_NO_CULL=1 evaluates every pair like the reference: images, n_contrib and every gradient
-    must be bit-identical with and without the culling -- the direct check of its safety margin."""
+    gsr_tile_band_mask).  GSR_DEBUG_NO_CULL in the call's debug mask evaluates every pair like the reference: images,
+    n_contrib and every gradient must be bit-identical with and without the culling -- the direct check of its safety
+    margin, also at the headline workload (C3: 9.2M instances, 4.6x C2's)."""
     _need_gpu()
+    from diff_gaussian_rasterization import _C
     dev = torch.device("cuda:0")
-    if case == "C2":
-        scene, cam, D = gsr_scene.make_config("C2")
+    if case in ("C2", "C3"):
+        scene, cam, D = gsr_scene.make_config(case)
         runs = [(scene, cam, D)]
     else:
         runs = []
@@ -175,53 +178,66 @@ def test_band_culling_changes_nothing(case):
             scene = gsr_scene.make_scene(P, mu, sh_degree=D, seed=seed)
             cam = gsr_scene.ring_camera(W, H, int(rng.integers(0, 8)), 8, radius=float(rng.uniform(0.3, 4.5)))
             runs.append((scene, cam, D))
-    prev = os.environ.get("GSR_NO_CULL")
-    try:
-        for scene, cam, D in runs:
-            dpix = torch.randn(3, cam.image_height, cam.image_width, generator=torch.Generator().manual_seed(1)).to(dev)
-            os.environ["GSR_NO_CULL"] = "0"
-            a = _direct(scene, cam, D, dpix, dev)
-            os.environ["GSR_NO_CULL"] = "1"
-            b = _direct(scene, cam, D, dpix, dev)
-            _same(a, b)
-    finally:
-        if prev is None:
-            os.environ.pop("GSR_NO_CULL", None)
-        else:
-            os.environ["GSR_NO_CULL"] = prev
+    for scene, cam, D in runs:
+        dpix = torch.randn(3, cam.image_height, cam.image_width, generator=torch.Generator().manual_seed(1)).to(dev)
+        a = _direct(scene, cam, D, dpix, dev)
+        b = _direct(scene, cam, D, dpix, dev, debug=_C.DEBUG_NO_CULL)
+        _same(a, b)
 
 
 def test_colour_kernel_beside_or_in_line_is_the_same():
     """The SH colour kernel of the forward runs on a helper stream beside the geometry kernel and the depth sort, forked
-    from and joined into the caller's stream inside gsr_forward_preprocess (api.hip).  GSR_SERIAL=1 runs it in line.
+    from and joined into the caller's stream inside gsr_forward_preprocess (api.hip).  GSR_DEBUG_SERIAL runs it in line.
     Both must give bit-identical images, state and gradients -- also when calls follow each other without a host sync in
     between and reuse the same buffers (a missed join would show as a stale colour in the next blend)."""
     _need_gpu()
+    from diff_gaussian_rasterization import _C
     dev = torch.device("cuda:0")
     scene, cam, D = gsr_scene.make_config("C2")
     dpix = torch.randn(3, cam.image_height, cam.image_width, generator=torch.Generator().manual_seed(1)).to(dev)
-    prev = os.environ.get("GSR_SERIAL")
-    try:
-        os.environ["GSR_SERIAL"] = "1"
-        ref = _direct(scene, cam, D, dpix, dev)
-        os.environ["GSR_SERIAL"] = "0"
-        for _ in range(5):   # back to back: the caching allocator hands the same buffers to consecutive calls
-            _same(ref, _direct(scene, cam, D, dpix, dev))
-        # a second scene in between changes every colour: nothing of it may survive into the next call
-        scene2 = gsr_scene.make_scene(scene.means3D.shape[0], -2.2, sh_degree=D, seed=7)
-        _direct(scene2, cam, D, dpix, dev)
+    ref = _direct(scene, cam, D, dpix, dev, debug=_C.DEBUG_SERIAL)
+    for _ in range(5):   # back to back: the caching allocator hands the same buffers to consecutive calls
         _same(ref, _direct(scene, cam, D, dpix, dev))
-        side = torch.cuda.Stream(device=dev)
-        side.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(side):
-            got = _direct(scene, cam, D, dpix, dev)
-        side.synchronize()
-        _same(ref, got)
-    finally:
-        if prev is None:
-            os.environ.pop("GSR_SERIAL", None)
-        else:
-            os.environ["GSR_SERIAL"] = prev
+    # a second scene in between changes every colour: nothing of it may survive into the next call
+    scene2 = gsr_scene.make_scene(scene.means3D.shape[0], -2.2, sh_degree=D, seed=7)
+    _direct(scene2, cam, D, dpix, dev)
+    _same(ref, _direct(scene, cam, D, dpix, dev))
+    side = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        got = _direct(scene, cam, D, dpix, dev)
+    side.synchronize()
+    _same(ref, got)
+
+
+def test_error_return_after_the_fork_still_joins_and_thread_release_frees():
+    """gsr_forward_preprocess forks the SH colour kernel onto a helper stream; a call that fails AFTER the fork
+    (prefiltered = 1 with a culled point -> GSR_ERR_PREFILTERED) must still leave the caller's stream ordered after that
+    kernel, because the caller may free `geometry` right away.  Here the failed call's geometry blob is handed back to
+    the allocator and immediately reused by a correct call on the same stream: its results must be the reference bits.
+    gsr_thread_release() then frees the thread's helper stream / events / pinned buffer, and the next call recreates them."""
+    _need_gpu()
+    from diff_gaussian_rasterization import _C
+    dev = torch.device("cuda:0")
+    scene = gsr_scene.make_scene(60_000, -3.5, sh_degree=3, seed=5)
+    cam = gsr_scene.ring_camera(320, 200, 1, 8, radius=1.0)   # camera inside the cloud: some points are culled
+    dpix = torch.randn(3, 200, 320, generator=torch.Generator().manual_seed(2)).to(dev)
+    ref = _direct(scene, cam, 3, dpix, dev, debug=_C.DEBUG_SERIAL)
+    st = util.hip_settings(scene, cam, 3, dev)
+    e = torch.empty(0, device=dev)
+    t = {k: getattr(scene, k).to(dev) for k in ("means3D", "shs", "opacities", "scales", "rotations")}
+    for _ in range(3):
+        with pytest.raises(RuntimeError, match="filtered although prefiltered"):
+            _C.rasterize_gaussians(st.bg, t["means3D"], e, t["opacities"], t["scales"], t["rotations"], 1.0, e, st.viewmatrix,
+                                   st.projmatrix, st.tanfovx, st.tanfovy, st.image_height, st.image_width, t["shs"], 3, st.campos,
+                                   True, False)
+        _same(ref, _direct(scene, cam, 3, dpix, dev))   # reuses the blob the failed call just dropped
+    torch.cuda.synchronize()
+    _C.thread_release()
+    _C.thread_release()   # idempotent
+    _same(ref, _direct(scene, cam, 3, dpix, dev))
+    torch.cuda.synchronize()
+    _C.thread_release()
 
 
 def test_bench_line_carries_the_contract_fields():

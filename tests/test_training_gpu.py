@@ -63,7 +63,7 @@ def test_fused_training_loop_converges_and_tracks_the_pytorch_loop():
 
     def run(fused, iters=40):
         pc, opt = make(FusedAdam if fused else torch.optim.Adam)
-        losses = []
+        losses, first_grads = [], None
         for it in range(iters):
             v = it % len(cams)
             m2 = torch.zeros_like(pc._xyz, requires_grad=True)
@@ -77,13 +77,22 @@ def test_fused_training_loop_converges_and_tracks_the_pytorch_loop():
                 loss = _stock_loss(image, gts[v])
             loss.backward()
             assert m2.grad is not None and float(m2.grad[:, 2].abs().max()) == 0.0   # the densification statistic's carrier
+            if it == 0:   # identical parameters on both sides: the gradients of this one step are compared directly
+                first_grads = [gr["params"][0].grad.detach().clone() for gr in opt.param_groups]
             opt.step()
             opt.zero_grad(set_to_none=True)
             losses.append(float(loss.detach()))
-        return losses, [p.detach().clone() for p in pc.parameters()]
+        return losses, [p.detach().clone() for p in pc.parameters()], first_grads
 
-    lf, pf = run(True)
-    lp, pp = run(False)
+    lf, pf, gf = run(True)
+    lp, pp, gp = run(False)
+    # (1) one identical step: fused leaf path (activations + their backward inside the kernels, fused loss) against PyTorch
+    # activations + stock loss around the drop-in rasterizer -- same parameters, so any difference here is arithmetic, not
+    # optimiser dynamics.  What is left for (2) below is Adam's amplification alone.
+    for n, a, b in zip(names, gf, gp):
+        e = float((a - b).abs().max()) / max(float(b.abs().max()), 1e-30)
+        print(f"step-0 gradient {n}: max|diff| / max|g| = {e:.2e}")
+        assert e <= 2e-5, (n, e)
     first, last = sum(lf[:3]) / 3, sum(lf[-3:]) / 3
     assert last < 0.6 * first, (first, last)
     # same mathematics, different fp32 evaluation order; Adam divides by sqrt(v) ~ |g| in its first steps,
@@ -93,8 +102,12 @@ def test_fused_training_loop_converges_and_tracks_the_pytorch_loop():
     print("loss fused  ", [round(v, 5) for v in lf[::4]])
     print("loss pytorch", [round(v, 5) for v in lp[::4]])
     print("rel diff    ", [f"{v:.1e}" for v in rel[::4]])
+    # (2) the trajectories: Adam's normalisation turns last-bit differences of tiny gradients into full-size steps of those
+    # elements, so the two loops drift apart slowly -- tight at the start, within 3 % over the first half, and bounded at
+    # the end of the 40 iterations
     assert max(rel[:8]) <= 1e-3, rel[:8]
-    assert max(rel) <= 1e-1, rel   # 40 Adam steps amplify last-bit differences of tiny gradients (2-5 % by then)
+    assert max(rel[:20]) <= 3e-2, rel[:20]
+    assert max(rel) <= 1e-1, rel
     for n, a, b in zip(names, pf, pp):
         d = float((a - b).abs().mean()) / max(float(b.abs().mean()), 1e-12)
         print(n, f"mean |diff| / mean |param| = {d:.2e}")

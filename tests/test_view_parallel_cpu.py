@@ -16,6 +16,40 @@ def test_shard_views_partition():
     assert view_parallel.shard_views(8, 3, 8) == [3]
 
 
+def test_gradient_exchange_ranges_cover_every_size_including_the_empty_scene():
+    """Part ranges: starts are multiples of 256, the parts cover [0, P) exactly, and P == 0 (an empty scene is legal at the
+    boundary, rasterize_points.cu:94) gives one empty part instead of raising."""
+    for P, parts in ((0, 2), (1, 2), (255, 3), (256, 2), (257, 2), (1500, 3), (10_000, 4), (1_000_000, 2)):
+        ex = view_parallel.GradientExchange(P, 16, "cpu", parts=parts)
+        assert all(f % 256 == 0 for f, _ in ex.ranges) and sum(c for _, c in ex.ranges) == P, (P, ex.ranges)
+        assert 1 <= len(ex.ranges) <= max(1, parts)
+        if P == 0:
+            assert ex.ranges == [(0, 0)]
+            ex.begin_step()
+            ex.submit(0, torch.zeros(3))
+            out = ex.finish(torch.zeros(0, 3), 3, rebuild_sh=False)
+            assert out["dL_dmean3D"].shape == (0, 3) and out["dL_dsh"].shape == (0, 16, 3)
+
+
+def test_densification_stats_update_keeps_the_tensors_the_kernel_was_given():
+    """kernel_tensors() hands views of the local accumulators to rasterizer objects and autograd contexts that keep them;
+    update() (the PyTorch form of the same bookkeeping) must write INTO them, or later kernel-epilogue maxima are lost."""
+    P = 6
+    stats = view_parallel.DensificationStats(P)
+    accum, denom, maxr = stats.kernel_tensors()          # captured before any update, like GaussianRasterizer(densify_stats=...)
+    ptrs = [t.data_ptr() for t in (accum, denom, maxr)]
+    stats.update(torch.ones(P, 3), torch.tensor([0, 3, 0, 9, 1, 0], dtype=torch.int32))
+    assert [t.data_ptr() for t in stats.kernel_tensors()] == ptrs
+    maxr[2] = 40.0                                        # what the kernel epilogue of a later view would write
+    accum[2] += 2.0
+    denom[2] += 1.0
+    stats.update(torch.ones(P, 3), torch.tensor([5, 1, 0, 2, 0, 0], dtype=torch.int32))
+    stats.sync()
+    assert stats.max_radii2D.tolist() == [5.0, 3.0, 40.0, 9.0, 1.0, 0.0]
+    assert stats.denom.flatten().tolist() == [1.0, 2.0, 1.0, 2.0, 1.0, 0.0]
+    assert abs(float(stats.xyz_gradient_accum[2]) - 2.0) < 1e-6
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -186,3 +220,19 @@ def test_bench_gpus_2_starts_two_ranks_without_a_launcher():
     r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run"], env=env2, capture_output=True,
                         text=True, timeout=120)
     assert r2.returncode != 0 and "WORLD_SIZE=1" in (r2.stderr + r2.stdout)
+
+
+def test_bench_rank_whose_peer_never_arrives_exits_nonzero_instead_of_hanging():
+    """The 8-GPU run is this code's first RCCL run: a rank that cannot form the group (or whose collective never completes)
+    must leave with a message and a non-zero code within --collective-timeout-s, so that launch_ranks stops the others."""
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
+               GSR_BENCH_BACKEND="gloo")
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run", "--collective-timeout-s", "4"],
+                       env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 3, (r.returncode, r.stderr[-500:])
+    assert "could not be formed" in r.stderr and time.time() - t0 < 60

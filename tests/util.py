@@ -7,6 +7,15 @@ import gsr_scene
 from oracle import oracle
 
 
+# error-versus-bar lines of the parity checks, kept so that tools/parity_report.py can write them to a file (pytest -q
+# drops what the tests print)
+PARITY_LOG = []
+
+
+def parity_log(text):
+    PARITY_LOG.append(text)
+
+
 def oracle_forward(scene, cam, D, margin=2e-5, colors_precomp=None, cov3D_precomp=None, scale_modifier=1.0,
                    use_sh=True, use_scale_rot=True):
     return oracle.forward(
