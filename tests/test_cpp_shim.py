@@ -53,7 +53,7 @@ def test_cpp_caller_through_the_reference_signature_matches_the_python_binding(t
     dev = torch.device("cuda:0")
     P, D, M, W, H = 2000, 3, 16, 200, 120
     scene = gsr_scene.make_scene(P, -3.0, sh_degree=D, seed=3)
-    cam = gsr_scene.ring_camera(W, H, 3, 8, radius=2.5)   # part of the scene is behind the camera
+    cam = gsr_scene.ring_camera(W, H, 3, 8, radius=1.0)   # inside the cloud: part of the scene is behind the camera
     dpix = torch.randn(3, H, W, generator=torch.Generator().manual_seed(7))
     inp, outp = tmp_path / "in.bin", tmp_path / "out.bin"
     with open(inp, "wb") as f:
