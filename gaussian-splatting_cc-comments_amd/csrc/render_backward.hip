@@ -19,6 +19,15 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 
 GSR_TILE_CLOCK_BUFFER(gsr_backward_tile_clock, gsr_debug_tile_clock_backward)
 
+// x + y of a pixel pair as ONE v_add_f32 on the pair's two registers.  Left to itself the compiler packs two such sums into a
+// v_pk_add_f32 and pays three v_mov_b32 to line the operands up (16 instructions for eight sums instead of 8).
+__device__ __forceinline__ float gsr_add_halves(v2f a)
+{
+	float r;
+	asm("v_add_f32_e32 %0, %1, %2" : "=v"(r) : "v"(a.x), "v"(a.y));
+	return r;
+}
+
 __global__ void __launch_bounds__(64 * GSR_WAVES_PER_WG) __attribute__((amdgpu_waves_per_eu(4, 4))) gsr_render_backward_wave_kernel(
 	int W, int H, int gx, int ntiles, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
 	const GsrSplat* __restrict__ splat, const uint32_t* __restrict__ slot_base, const float* __restrict__ bg,
@@ -31,10 +40,15 @@ __global__ void __launch_bounds__(64 * GSR_WAVES_PER_WG) __attribute__((amdgpu_w
 	// for v_pk_*_f32 (the compiler otherwise spends one v_mov per scalar per instance on the duplication)
 	__shared__ float4 s_rec[GSR_WAVES_PER_WG][5][64];
 	__shared__ uint32_t s_bands[GSR_WAVES_PER_WG][64];
+	// transposition area of the per-instance wave reduction: lane l stores its eight partials at row l (row stride 9 words:
+	// 9 is odd, so the 64 rows of one store instruction fall into 64 different banks), then the eight lanes of group c read
+	// column c, eight rows each
+	__shared__ float s_red[GSR_WAVES_PER_WG][64 * 9 + 8];
 	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 	const int slot_id = blockIdx.x * GSR_WAVES_PER_WG + wave;
 	if (slot_id >= ntiles) return;  // wave-uniform; no barriers below
 	GSR_TILE_CLOCK_START();
+	GSR_TILE_STAT(unsigned long long st_staged = 0; unsigned long long st_pairs = 0; unsigned long long st_pairs_hit = 0; unsigned long long st_reductions = 0; unsigned long long st_lanes_hit = 0;)
 	// workgroups are dispatched in index order: tile_order lists the tiles by descending work, so the long tiles
 	// start first and the short ones fill the end of the launch (binning.hip gsr_tile_order_kernel)
 	const int tile = (int)tile_order[slot_id];
@@ -101,14 +115,18 @@ __global__ void __launch_bounds__(64 * GSR_WAVES_PER_WG) __attribute__((amdgpu_w
 		sbase = slot_base[id];
 	}
 	uint32_t id_next = (64 + lane < n) ? plist[n - 1 - (64 + lane)] : 0u;
-	const int out_index = gsr_bfly_index(lane >> 3);  // which of v[0..7] this lane's 8-lane group ends up holding
+	const int out_index = lane >> 3;                  // 8-lane group c ends up holding the wave total of v[c]
+	float* const red_w = s_red[wave] + lane * 9;                       // this lane's row
+	const float* const red_r = s_red[wave] + (lane & 7) * 9 + (lane >> 3);   // column lane / 8, rows (lane % 8) + 8 k
 	const float out_scale = (out_index >= 2 && out_index <= 4) ? -0.5f : 1.0f;
+	const float k01 = out_index == 0 ? -ddelx_dx : -ddely_dy;   // backward.cu:574-575: dL/dmean2D is scaled by 0.5 W / 0.5 H
 
 	for (int base = 0; base < n; base += 64) {
 		const uint32_t bands = (base + lane < n) ? (cull ? gsr_tile_band_mask(ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, x0f, y0f) : 0xFu) : 0u;
 		const bool keep = bands != 0u;
 		const unsigned long long mask = __builtin_amdgcn_ballot_w64(keep);
 		const int cnt = __popcll(mask);
+		GSR_TILE_STAT(st_staged += (unsigned)cnt;)
 		if (keep) {
 			const int pos = gsr_mbcnt(mask);
 			const uint32_t rmin = __float_as_uint(rc.z), rwh = __float_as_uint(rc.w);
@@ -165,7 +183,9 @@ __global__ void __launch_bounds__(64 * GSR_WAVES_PER_WG) __attribute__((amdgpu_w
 				// bool costs a v_cndmask + v_cmp round trip through a VGPR
 				const unsigned long long hits = (__builtin_amdgcn_ballot_w64(c0) & __builtin_amdgcn_ballot_w64(p0) & __builtin_amdgcn_ballot_w64(a0)) |
 				                                (__builtin_amdgcn_ballot_w64(c1) & __builtin_amdgcn_ballot_w64(p1) & __builtin_amdgcn_ballot_w64(a1));
+				GSR_TILE_STAT(st_pairs++;)
 				if (hits == 0ull) continue;  // wave-uniform
+				GSR_TILE_STAT(st_pairs_hit++; st_lanes_hit += (unsigned)__popcll(hits);)
 				any |= hits;  // (lanes without a hit add exact zeros below)
 				// A pixel that did not hit runs the same update with alpha = 0, which is the identity on its state
 				// bit for bit (1 - 0 = 1, rcp(1) = 1, T * 1 = T, 0 * c + 1 * acc = acc): no per-state selects
@@ -211,23 +231,32 @@ __global__ void __launch_bounds__(64 * GSR_WAVES_PER_WG) __attribute__((amdgpu_w
 				acc[4] = __builtin_elementwise_fma(fdy, dy, acc[4]);
 			}
 			if (any) {  // wave-uniform
+				GSR_TILE_STAT(st_reductions++;)
 				float v[GSR_BWD_NV];
 #pragma unroll
-				for (int i = 0; i < GSR_BWD_NV; i++) v[i] = acc[i].x + acc[i].y;
-				const float t8 = gsr_bfly8(v, lane);           // group g holds the total of v[gsr_bfly_index(g)]
+				for (int i = 0; i < GSR_BWD_NV; i++) v[i] = gsr_add_halves(acc[i]);
+				// the wave reduction of the first eight values through LDS: 64 x 8 partials in, transposed out -- the cross-lane work
+				// is LDS traffic (its own issue port) plus 7 adds and the 3 DPP steps inside an 8-lane group, instead of 6 lane swaps,
+				// 6 adds, 2 selects and 4 DPP steps on the vector ALU, which is what bounds this kernel.  A wave's LDS operations
+				// execute in program order: the loads below see all 64 rows, and the next instance's stores come after them.
+#pragma unroll
+				for (int i = 0; i < 8; i++) red_w[i] = v[i];
+				float col[8];
+#pragma unroll
+				for (int k = 0; k < 8; k++) col[k] = red_r[72 * k];
+				// the ninth value's DPP chain runs while the LDS round trip is under way
+				__builtin_amdgcn_sched_barrier(0);
 				const float t9 = gsr_wave_sum_to_lane63(v[8]);  // lane 63 holds the total of v[8]
-				// v[0] ends in group 0 (lane 0), v[1] in group 4 (lane 32): scalar broadcasts
-				const float sx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, t8), 0));
-				const float sy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, t8), 32));
-				// the slot is the same in every lane: a scalar, so the store addresses are SGPR base + lane-constant offset
+				__builtin_amdgcn_sched_barrier(0);
+				const float tcol = ((col[0] + col[1]) + (col[2] + col[3])) + ((col[4] + col[5]) + (col[6] + col[7]));
+				const float t8 = gsr_sum8(tcol);                // group c holds the total of v[c]
+				// dL/dmean2D: group 0 (sum f dx = sx) needs sy, group 1 (sy) needs sx -- the partner half row, one DPP move; the
+				// same products and the same FMA as the scalar form below (a sx + b sy with a = -2 (-0.5 a)), so the same bits
+				const float other = gsr_dpp_mov<0x128, 0xF, 0xF, true>(t8);  // row_ror:8
+				const float r01 = k01 * __builtin_fmaf(-2.0f, (out_index == 0 ? CA.x : CC.x) * t8, CB.x * other);
 				const uint32_t slot = __builtin_amdgcn_readfirstlane(__float_as_uint(R4.w));
 				float* out = reinterpret_cast<float*>(slots + slot);
-				// every lane evaluates all three forms and selects by its (loop-invariant) output index: no exec-mask regions
-				// a sx + b sy with a = -2 CA: fma(-2, CA sx, b sy) rounds once, after two exact scalings -- the bits of the plain sum
-				const float rx = -ddelx_dx * __builtin_fmaf(-2.0f, CA.x * sx, CB.x * sy);  // dL/dmean2D.x
-				const float ry = -ddely_dy * __builtin_fmaf(-2.0f, CC.x * sy, CB.x * sx);  // dL/dmean2D.y
-				const float rk = out_scale * t8;                       // dL/dconic .x .y .w (x -0.5); opacity and colour as they are
-				const float r = out_index == 0 ? rx : (out_index == 1 ? ry : rk);
+				const float r = out_index < 2 ? r01 : out_scale * t8;   // dL/dconic .x .y .w (x -0.5); opacity and colour as they are
 				if ((lane & 7) == 0) out[out_index] = r;
 				if (lane == 63) {
 					out[8] = t9;
@@ -237,7 +266,7 @@ __global__ void __launch_bounds__(64 * GSR_WAVES_PER_WG) __attribute__((amdgpu_w
 		}
 		__builtin_amdgcn_wave_barrier();
 	}
-	GSR_TILE_CLOCK_STOP(gsr_backward_tile_clock, tile, lane);
+	GSR_TILE_CLOCK_STOP(gsr_backward_tile_clock, tile, lane, st_staged | (st_pairs << 20) | (st_pairs_hit << 42), st_reductions | (st_lanes_hit << 24));
 }
 
 void gsr_launch_render_backward(int W, int H, GsrImage img, const uint32_t* point_list, const GsrSplat* splat,

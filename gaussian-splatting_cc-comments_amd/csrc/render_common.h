@@ -23,21 +23,29 @@
 #define GSR_TILE_CLOCK_BUFFER(sym, setter)                                                           \
 	__device__ unsigned long long* sym = nullptr;                                                    \
 	extern "C" int setter(unsigned long long* buf) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(sym), &buf, sizeof(buf)); }
-#define GSR_TILE_CLOCK_START() const unsigned long long gsr_tc0 = __builtin_amdgcn_s_memrealtime()
-#define GSR_TILE_CLOCK_STOP(sym, tile, lane)                                                         \
+// eight words per tile: start / end on the 100 MHz constant clock, HW_ID, XCC_ID, start / end on the shader clock
+// (s_memtime: with the pair above, the clock the wave actually ran at), two words of work counters (sa, sb)
+#define GSR_TILE_CLOCK_START() const unsigned long long gsr_tc0 = __builtin_amdgcn_s_memrealtime(), gsr_tcc0 = __builtin_amdgcn_s_memtime()
+#define GSR_TILE_CLOCK_STOP(sym, tile, lane, sa, sb)                                                 \
 	do {                                                                                             \
 		unsigned long long* gsr_tc = sym;                                                            \
 		if (gsr_tc && (lane) == 0) {                                                                 \
-			gsr_tc[4 * (size_t)(tile)] = gsr_tc0;                                                    \
-			gsr_tc[4 * (size_t)(tile) + 1] = __builtin_amdgcn_s_memrealtime();                       \
-			gsr_tc[4 * (size_t)(tile) + 2] = __builtin_amdgcn_s_getreg((31 << 11) | 4);  /* HW_REG_HW_ID */  \
-			gsr_tc[4 * (size_t)(tile) + 3] = __builtin_amdgcn_s_getreg((31 << 11) | 20); /* HW_REG_XCC_ID */ \
+			gsr_tc[8 * (size_t)(tile)] = gsr_tc0;                                                    \
+			gsr_tc[8 * (size_t)(tile) + 1] = __builtin_amdgcn_s_memrealtime();                       \
+			gsr_tc[8 * (size_t)(tile) + 2] = __builtin_amdgcn_s_getreg((31 << 11) | 4);  /* HW_REG_HW_ID */  \
+			gsr_tc[8 * (size_t)(tile) + 3] = __builtin_amdgcn_s_getreg((31 << 11) | 20); /* HW_REG_XCC_ID */ \
+			gsr_tc[8 * (size_t)(tile) + 4] = gsr_tcc0;                                               \
+			gsr_tc[8 * (size_t)(tile) + 5] = __builtin_amdgcn_s_memtime();                           \
+			gsr_tc[8 * (size_t)(tile) + 6] = (sa);                                                   \
+			gsr_tc[8 * (size_t)(tile) + 7] = (sb);                                                   \
 		}                                                                                            \
 	} while (0)
+#define GSR_TILE_STAT(x) x
 #else
 #define GSR_TILE_CLOCK_BUFFER(sym, setter)
 #define GSR_TILE_CLOCK_START()
-#define GSR_TILE_CLOCK_STOP(sym, tile, lane)
+#define GSR_TILE_CLOCK_STOP(sym, tile, lane, sa, sb)
+#define GSR_TILE_STAT(x)
 #endif
 
 // Conservative, exact-result-preserving culling.  alpha = o*exp(-q/2) with
@@ -113,52 +121,11 @@ __device__ __forceinline__ float gsr_pair_power_halved(float axh2, float bdx, fl
 	return __fsub_rn(__fadd_rn(axh2, cyh2), __fmul_rn(bdx, dy));
 }
 
-// ---- wave64 butterfly reduction of 8 values (gfx950 v_permlane{32,16}_swap + DPP) ----------------
-// Each fold halves the number of live registers instead of reducing every register over all 64
-// lanes: 8 values cost 18 cross-lane ops instead of 48.  On return every lane of the 8-lane group g
-// (lanes 8g .. 8g+7) holds the wave total of value gsr_bfly_index(g).
-// Inline asm, not __builtin_amdgcn_permlane{32,16}_swap: with ROCm 7.2's hipcc the sum r[0] + r[1] of
-// the builtin's two results is emitted as vdst + vdst (second result dropped; verified with
-// tools/bfly_probe.hip on gfx950).  The leading s_nop 1 is the wait the compiler itself places
-// between a VALU write of an operand and the swap.
-__device__ __forceinline__ float gsr_fold32(float a, float b)
-{
-	// swaps a[32..63] with b[0..31]; the sum is a folded over the halves in lanes < 32, b in lanes >= 32
-	asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
-	return a + b;
-}
-
-__device__ __forceinline__ float gsr_fold16(float a, float b)
-{
-	// swaps the odd 16-lane rows of a with the even rows of b; rows of the sum: a(r0+r1) b(r0+r1) a(r2+r3) b(r2+r3)
-	asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
-	return a + b;
-}
-
-__device__ __forceinline__ float gsr_fold8(float a, float b, bool upper_half_row)
-{
-	const float keep = upper_half_row ? b : a, send = upper_half_row ? a : b;
-	return keep + gsr_dpp_mov<0x128, 0xF, 0xF, true>(send);  // row_ror:8 = partner in the other half row
-}
-
+// sum over the eight lanes of each 8-lane group (three DPP steps); every lane of the group ends with the group's total
 __device__ __forceinline__ float gsr_sum8(float v)
 {
 	v += gsr_dpp_mov<0xB1, 0xF, 0xF, true>(v);   // quad_perm [1,0,3,2]
 	v += gsr_dpp_mov<0x4E, 0xF, 0xF, true>(v);   // quad_perm [2,3,0,1]
 	v += gsr_dpp_mov<0x141, 0xF, 0xF, true>(v);  // row_half_mirror
 	return v;
-}
-
-// value index held by 8-lane group g after gsr_bfly8()
-__device__ __forceinline__ int gsr_bfly_index(int g)
-{
-	return ((g & 1) << 2) | (g & 2) | ((g >> 2) & 1);  // {0,4,2,6,1,5,3,7}
-}
-
-__device__ __forceinline__ float gsr_bfly8(const float* v, int lane)
-{
-	const float w0 = gsr_fold32(v[0], v[1]), w1 = gsr_fold32(v[2], v[3]);
-	const float w2 = gsr_fold32(v[4], v[5]), w3 = gsr_fold32(v[6], v[7]);
-	const float u0 = gsr_fold16(w0, w1), u1 = gsr_fold16(w2, w3);
-	return gsr_sum8(gsr_fold8(u0, u1, (lane & 8) != 0));
 }

@@ -154,7 +154,7 @@ __global__ void __launch_bounds__(64 * GSR_WAVES_PER_WG) gsr_render_forward_wave
 #pragma unroll
 	for (int off = 32; off > 0; off >>= 1) m = max(m, (uint32_t)__shfl_down(m, off, 64));
 	if (lane == 0) tile_max_contrib[tile] = m;
-	GSR_TILE_CLOCK_STOP(gsr_forward_tile_clock, tile, lane);
+	GSR_TILE_CLOCK_STOP(gsr_forward_tile_clock, tile, lane, 0ull, 0ull);
 }
 
 void gsr_launch_render_forward(int W, int H, GsrImage img, const uint32_t* point_list, const GsrSplat* splat,

@@ -14,6 +14,7 @@ cd /tmp
 BENCH="python3 $ROOT/bench.py --config $CFG --steps 10 --warmup 3 --no-cpu-baseline --no-extras"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- $BENCH > "$OUT/trace.log" 2>&1 || { tail -5 "$OUT/trace.log"; exit 1; }
 cp "$(ls "$OUT"/trace/*/*kernel_stats.csv | head -1)" "$OUT/kernel_stats.csv"
+python3 "$ROOT/tools/timeline.py" "$(ls "$OUT"/trace/*/*kernel_trace.csv | head -1)" 10 > "$OUT/timeline.txt" 2>&1 || tail -3 "$OUT/timeline.txt"
 BENCH="python3 $ROOT/bench.py --config $CFG --steps 5 --warmup 2 --no-cpu-baseline --no-extras"
 n=0
 for counters in "FETCH_SIZE" "WRITE_SIZE" \

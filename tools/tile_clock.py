@@ -56,6 +56,16 @@ def analyse(name, rec, waves_per_simd, out):
     resident = np.cumsum(delta)[:ticks]
     slots = nsimd * waves_per_simd
     print(f"== {name}: {len(rec)} waves on {nsimd} SIMDs, launch span {span:.1f} us", file=out)
+    if rec.shape[1] >= 6:   # shader clock over the waves' own lifetimes (s_memtime ticks per 100 MHz tick)
+        ghz = float((rec[:, 5] - rec[:, 4]).sum()) / float((t1 - t0).sum()) * 0.1
+        print(f"   shader clock while the waves ran: {ghz:.3f} GHz (s_memtime / s_memrealtime over all waves)", file=out)
+    if rec.shape[1] >= 8 and rec[:, 6].any():
+        sa, sb = rec[:, 6], rec[:, 7]
+        staged, pairs, pairs_hit = int((sa & 0xFFFFF).sum()), int(((sa >> 20) & 0x3FFFFF).sum()), int(((sa >> 42) & 0x3FFFFF).sum())
+        red, lanes = int((sb & 0xFFFFFF).sum()), int((sb >> 24).sum())
+        print(f"   work: {staged} instances staged after the band cull, {pairs} pixel pairs evaluated ({pairs / max(staged, 1):.2f} per staged instance), "
+              f"{pairs_hit} of them with a hit ({pairs_hit / max(pairs, 1):.2f}), {lanes / max(pairs_hit, 1):.1f} of 64 lanes hit per such pair, "
+              f"{red} wave reductions ({red / max(staged, 1):.2f} per staged instance)", file=out)
     print(f"   wave duration: mean {dur.mean():.1f}  median {np.median(dur):.1f}  p90 {np.percentile(dur, 90):.1f}  max {dur.max():.1f} us;"
           f"  waves per SIMD: min {count.min()} mean {count.mean():.2f} max {count.max()}", file=out)
     print(f"   sum of wave durations {dur.sum() / 1e3:.2f} ms = {dur.sum() / span:.0f} resident waves on average "
@@ -106,7 +116,7 @@ def main():
     rasterizer = GaussianRasterizer(settings)
     dpix = to(torch.randn(3, H, W, generator=torch.Generator().manual_seed(1)))
     ntiles = ((W + 15) // 16) * ((H + 15) // 16)
-    bufs = {k: torch.zeros(ntiles, 4, dtype=torch.int64, device=dev) for k in ("forward", "backward")}
+    bufs = {k: torch.zeros(ntiles, 8, dtype=torch.int64, device=dev) for k in ("forward", "backward")}
 
     captured = {}
     orig = _C.rasterize_gaussians

@@ -1,0 +1,43 @@
+"""Where a step's time goes on the GPU timeline, from a rocprofv3 --kernel-trace csv (*_kernel_trace.csv).
+
+    python tools/timeline.py gpurun_out/<tag>/trace/*/*_kernel_trace.csv [last_n_steps]
+
+A step starts at each gsr_preprocess_kernel dispatch.  For the last N complete steps prints, per dispatch position in the
+step, the median start offset, duration and the idle gap in front of it (start minus the latest end of everything
+dispatched before it in the step -- kernels on the helper stream overlap, so the gap is taken against the running
+maximum of the ends), then the sums: kernel time on the critical path, idle time, step length."""
+import csv
+import statistics
+import sys
+
+path = sys.argv[1]
+last = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+rows = []
+for r in csv.DictReader(open(path)):
+    name = r["Kernel_Name"].split("(")[0].replace("void ", "")
+    rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), name))
+rows.sort()
+starts = [i for i, r in enumerate(rows) if r[2].startswith("gsr_preprocess_kernel")]
+steps = [rows[a:b] for a, b in zip(starts[:-1], starts[1:])]
+# keep the steps of the most common length (the timed ones; per-kernel-table steps run the colour kernel in line)
+steps = [s for s in steps if s and s[-1][2].startswith("gsr_gaussian_backward")]
+n = statistics.mode(len(s) for s in steps)
+steps = [s for s in steps if len(s) == n][-last:]
+print(f"{len(steps)} steps of {n} dispatches each")
+print(f"{'#':>2} {'kernel':44s} {'start us':>9} {'dur us':>8} {'gap us':>7}")
+tot_gap = tot_busy = 0.0
+for k in range(n):
+    st, du, gp = [], [], []
+    for s in steps:
+        t0 = s[0][0]
+        end_before = max([e for (_, e, _) in s[:k]], default=t0)
+        st.append((s[k][0] - t0) / 1e3)
+        du.append((s[k][1] - s[k][0]) / 1e3)
+        gp.append((s[k][0] - end_before) / 1e3)
+    g = statistics.median(gp)
+    print(f"{k:2d} {steps[0][k][2][:44]:44s} {statistics.median(st):9.1f} {statistics.median(du):8.1f} {g:7.1f}")
+    tot_gap += max(g, 0.0)
+lens = [(max(e for _, e, _ in s) - s[0][0]) / 1e3 for s in steps]
+period = [(b[0][0] - a[0][0]) / 1e3 for a, b in zip(steps[:-1], steps[1:]) if b[0][0] - a[0][0] < 3 * (a[-1][1] - a[0][0])]
+print(f"first start -> last end: median {statistics.median(lens):.1f} us; idle gaps inside: {tot_gap:.1f} us; "
+      f"step period (start to next start): median {statistics.median(period) if period else float('nan'):.1f} us")

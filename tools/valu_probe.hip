@@ -12,8 +12,8 @@
 typedef float v2f __attribute__((ext_vector_type(2)));
 #define ITERS 2048
 
-enum { K_FMA, K_PKFMA, K_EXP, K_RCP, K_MIX, K_CNDMASK, K_DPP, K_CNDMASK_S, K_CMP_CND, K_PKMUL, K_CMP, K_CMP_S, K_MOV, K_MAX, K_PERM32, K_NKINDS };
-static const char* KNAME[] = {"v_fma_f32", "v_pk_fma_f32", "v_exp_f32", "v_rcp_f32", "7 v_fma + 1 v_exp", "v_cndmask_b32 vcc", "v_add_f32 dpp", "v_cndmask_b32 sgpr", "v_cmp + v_cndmask", "v_pk_mul_f32", "v_cmp_gt_f32 vcc", "v_cmp_gt_f32 sgpr", "v_mov_b32", "v_max_f32", "v_permlane32_swap"};
+enum { K_FMA, K_PKFMA, K_EXP, K_RCP, K_MIX, K_CNDMASK, K_DPP, K_CNDMASK_S, K_CMP_CND, K_PKMUL, K_CMP, K_CMP_S, K_MOV, K_MAX, K_PERM32, K_MUL2, K_FMAC2, K_BLEND, K_NKINDS };
+static const char* KNAME[] = {"v_fma_f32", "v_pk_fma_f32", "v_exp_f32", "v_rcp_f32", "7 v_fma + 1 v_exp", "v_cndmask_b32 vcc", "v_add_f32 dpp", "v_cndmask_b32 sgpr", "v_cmp + v_cndmask", "v_pk_mul_f32", "v_cmp_gt_f32 vcc", "v_cmp_gt_f32 sgpr", "v_mov_b32", "v_max_f32", "v_permlane32_swap", "v_mul_f32_e32", "v_fmac_f32_e32", "forward-blend mix"};
 
 template <int KIND>
 __global__ void __launch_bounds__(1024) probe(float* out, unsigned long long* stamps, unsigned long long* sched)
@@ -49,6 +49,19 @@ __global__ void __launch_bounds__(1024) probe(float* out, unsigned long long* st
 				else if (KIND == K_MOV) asm volatile("v_mov_b32 %0, %1" : "=v"(a[i]) : "v"(b));
 				else if (KIND == K_MAX) asm volatile("v_max_f32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
 				else if (KIND == K_PERM32) asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(a[i]), "+v"(a[(i + 1) & 7]));
+				else if (KIND == K_MUL2) asm volatile("v_mul_f32_e32 %0, %1, %0" : "+v"(a[i]) : "v"(b));
+				else if (KIND == K_FMAC2) asm volatile("v_fmac_f32_e32 %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
+				else if (KIND == K_BLEND) {
+					// the instruction classes of one band of the forward blend (render_forward.hip), 8 instructions per accumulator
+					// per round: 5 VOP2 arithmetic, 1 compare into an SGPR pair, 1 select by an SGPR mask, and every other accumulator
+					// a v_exp_f32 in place of one multiply (1 transcendental per 16, the kernel has 1 per 22)
+					asm volatile("v_sub_f32_e32 %0, %0, %1\n\tv_mul_f32_e32 %0, %1, %0\n\tv_fmac_f32_e32 %0, %1, %2\n\tv_mul_f32_e32 %0, %1, %0"
+					             : "+v"(a[i]) : "v"(b), "v"(c));
+					if (i & 1) asm volatile("v_exp_f32 %0, %0" : "+v"(a[i]));
+					else asm volatile("v_min_f32_e32 %0, %1, %0" : "+v"(a[i]) : "v"(b));
+					asm volatile("v_cmp_gt_f32 %0, %1, %2\n\tv_cndmask_b32 %1, %1, %2, %3\n\tv_fmac_f32_e32 %1, %2, %4"
+					             : "=&s"(sm[i & 3]), "+v"(a[i]) : "v"(b), "s"(smask), "v"(c));
+				}
 				else if (KIND == K_DPP) asm volatile("v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(a[i]));
 			}
 		}
@@ -72,9 +85,11 @@ __global__ void __launch_bounds__(1024) probe(float* out, unsigned long long* st
 template <int KIND>
 static void run(int w, float* out, unsigned long long* stamps, unsigned long long* h, unsigned long long* sched)
 {
-	const int per_cu = w == 8 ? 2 : 1, threads = w == 8 ? 1024 : 256 * w;
+	// w workgroups of 256 threads (one wave per SIMD each) per CU: a workgroup's LDS is sized so that exactly w fit a CU's 160 KB
+	const int per_cu = w, threads = 256;
 	const int nwg = 256 * per_cu, nwaves = nwg * threads / 64;
-	const size_t lds = (160 * 1024) / per_cu / 2 + 1024;  // more than half of a CU's share: exactly per_cu workgroups per CU
+	const size_t lds = (size_t)(160 * 1024) / (w + 1) + 1024;
+	const double per_wave_instr = (KIND == K_BLEND) ? 8.0 : (KIND == K_CMP_CND ? 2.0 : 1.0);
 	hipFuncSetAttribute((const void*)probe<KIND>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 	hipEvent_t e0, e1;
 	hipEventCreate(&e0); hipEventCreate(&e1);
@@ -89,7 +104,7 @@ static void run(int w, float* out, unsigned long long* stamps, unsigned long lon
 	double cyc = 0, real = 0;
 	for (int i = 0; i < nwaves; i++) { cyc += (double)h[2 * i]; real += (double)h[2 * i + 1]; }
 	const double clock_ghz = cyc / real * 0.1;
-	const double instr_per_wave = (double)ITERS * 64.0;
+	const double instr_per_wave = (double)ITERS * 64.0 * per_wave_instr;
 	// in-kernel: cycles one wave needed per instruction; per SIMD: w waves share it
 	const double cyc_per_instr_wave = (cyc / nwaves) / instr_per_wave;
 	const double cyc_per_instr_simd = cyc_per_instr_wave / w;
@@ -115,8 +130,10 @@ static void run(int w, float* out, unsigned long long* stamps, unsigned long lon
 		printf("; first start -> last start %.1f us, first start -> last end %.1f us\n", (smax - tmin) * 0.01, (tmax - tmin) * 0.01);
 		free(hs);
 	}
-	printf("%-22s w=%d  kernel %.3f ms  clock %.2f GHz  cycles/instr: per wave %.2f, per SIMD %.2f (in-kernel stamps) %.2f (kernel wall time)\n",
-	       KNAME[KIND], w, ms, clock_ghz, cyc_per_instr_wave, cyc_per_instr_simd, wall_cyc_per_instr_simd);
+	// the roof in time units, free of any clock estimate: wave64 VALU instructions the whole chip issued per second
+	const double ginstr_per_s = instr_per_wave * nwaves / (ms * 1e-3) * 1e-9;
+	printf("%-22s w=%d  kernel %.3f ms  clock %.2f GHz  cycles/instr: per wave %.2f, per SIMD %.2f (in-kernel stamps) %.2f (kernel wall time)  chip rate %.0f G instr/s\n",
+	       KNAME[KIND], w, ms, clock_ghz, cyc_per_instr_wave, cyc_per_instr_simd, wall_cyc_per_instr_simd, ginstr_per_s);
 }
 
 int main()
@@ -127,8 +144,8 @@ int main()
 	unsigned long long* sched;
 	hipMalloc(&sched, 8192 * 32);
 	unsigned long long* h = (unsigned long long*)malloc(8192 * 16);
-	const int ws[] = {1, 4, 8};
-	for (int wi = 0; wi < 3; wi++) {
+	const int ws[] = {1, 4, 5, 8};
+	for (int wi = 0; wi < 4; wi++) {
 		const int w = ws[wi];
 		run<K_FMA>(w, out, stamps, h, sched);
 		run<K_PKFMA>(w, out, stamps, h, sched);
@@ -145,6 +162,9 @@ int main()
 		run<K_MOV>(w, out, stamps, h, sched);
 		run<K_MAX>(w, out, stamps, h, sched);
 		run<K_PERM32>(w, out, stamps, h, sched);
+		run<K_MUL2>(w, out, stamps, h, sched);
+		run<K_FMAC2>(w, out, stamps, h, sched);
+		run<K_BLEND>(w, out, stamps, h, sched);
 	}
 	return 0;
 }
