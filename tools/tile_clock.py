@@ -94,6 +94,8 @@ def main():
     ap.add_argument("--config", default="C3")
     ap.add_argument("--out", default=None)
     ap.add_argument("--dump", default=None, help="npz with the raw clocks and the dispatch keys")
+    ap.add_argument("--scene", default="uniform", choices=["uniform", "blob", "lowop"],
+                    help="uniform: the benchmark scene of --config; blob / lowop: the non-uniform 1M-Gaussian scenes of tools/skew_bench.py")
     ap.add_argument("--measured-key", action="store_true", help="also dispatch the backward by its own measured durations")
     a = ap.parse_args()
     if not os.path.exists(TWIN):
@@ -104,6 +106,10 @@ def main():
     dev = torch.device("cuda:0")
     P, W, H, D, mu = gsr_scene.CONFIGS[a.config]
     scene = gsr_scene.make_scene(P, mu, D, seed=0)
+    if a.scene != "uniform":
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import skew_bench
+        scene = skew_bench.make_skewed_scene(a.scene, P, mu, D)
     cam = gsr_scene.make_camera(W, H)
     to = lambda t: t.to(dev)
     params = dict(means3D=to(scene.means3D).requires_grad_(True), shs=to(scene.shs).requires_grad_(True),
@@ -134,7 +140,7 @@ def main():
         color, _ = rasterizer(means3D=params["means3D"], means2D=means2D, **{k: v for k, v in params.items() if k != "means3D"})
         color.backward(dpix)
 
-    for _ in range(5):
+    for _ in range(40):   # the first steps of a fresh process run at a lower shader clock (bench.py, settling steps)
         step()
     torch.cuda.synchronize()
     for k, b in bufs.items():
@@ -146,7 +152,7 @@ def main():
     for k in bufs:
         getattr(L, f"gsr_debug_tile_clock_{k}")(None)
     out = open(a.out, "w") if a.out else sys.stdout
-    print(f"# tools/tile_clock.py --config {a.config}: P={P} {W}x{H}, {ntiles} tiles, one wave64 per tile; clocks on the 100 MHz constant clock", file=out)
+    print(f"# tools/tile_clock.py --config {a.config} --scene {a.scene}: P={P} {W}x{H}, {ntiles} tiles, one wave64 per tile; clocks on the 100 MHz constant clock", file=out)
     analyse("render_forward (<= 5 waves per SIMD by its 88 VGPRs)", bufs["forward"].cpu().numpy(), 5, out)
     analyse("render_backward (4 waves per SIMD, 128 VGPRs)", bufs["backward"].cpu().numpy(), 4, out)
     # how well does the dispatch key predict a tile's duration?
