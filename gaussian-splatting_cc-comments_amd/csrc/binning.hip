@@ -74,7 +74,7 @@ void gsr_launch_sorted_block_sums(GsrGeometry g, int P, int result_in_alt, hipSt
 // (measured 2.5x write amplification).  Order inside a Gaussian: y outer, x inner
 // (rasterizer_impl.cu:107-118).
 __global__ void __launch_bounds__(GSR_PREPROCESS_BLOCK) gsr_duplicate_keys_kernel(GsrGeometry g, int P, uint32_t gx,
-                                                                                 uint32_t* __restrict__ keys,
+                                                                                 void* __restrict__ keys_, int key_bytes,
                                                                                  uint32_t* __restrict__ vals,
                                                                                  uint32_t* __restrict__ clear, size_t clear_words)
 {
@@ -82,6 +82,8 @@ __global__ void __launch_bounds__(GSR_PREPROCESS_BLOCK) gsr_duplicate_keys_kerne
 	for (size_t w = (size_t)blockIdx.x * GSR_PREPROCESS_BLOCK + threadIdx.x; w < clear_words; w += (size_t)gridDim.x * GSR_PREPROCESS_BLOCK)
 		clear[w] = 0u;
 	const uint32_t* __restrict__ perm = g.status[2] ? g.perm_alt : g.perm;  // where the depth sort left its result
+	uint32_t* __restrict__ const keys32 = static_cast<uint32_t*>(keys_);      // tile ids as 32-bit words, or (every id < 65 536)
+	uint16_t* __restrict__ const keys16 = static_cast<uint16_t*>(keys_);      // as 16-bit ones: the tile sort moves a quarter less
 	__shared__ uint32_t lds[GSR_PREPROCESS_BLOCK / 64];
 	__shared__ uint4 s_own[GSR_PREPROCESS_BLOCK / 64][64];       // per Gaussian: start, minx | miny << 16, rectangle width, id
 	__shared__ uint32_t s_flag[GSR_PREPROCESS_BLOCK / 64][64];   // per position of the current row: lane + 1 of the Gaussian that starts there
@@ -163,16 +165,17 @@ __global__ void __launch_bounds__(GSR_PREPROCESS_BLOCK) gsr_duplicate_keys_kerne
 			q = k / ww;
 		}
 		const uint32_t y = (rm >> 16) + q, x = (rm & 0xffffu) + (k - q * ww);
-		keys[wave_first + j] = y * gx + x;
+		if (key_bytes == 2) keys16[wave_first + j] = (uint16_t)(y * gx + x);
+		else keys32[wave_first + j] = y * gx + x;
 		vals[wave_first + j] = own.w;
 	}
 }
 
-void gsr_launch_duplicate_keys(GsrGeometry g, int P, int W, uint32_t* keys, uint32_t* vals, uint32_t* clear, size_t clear_words, hipStream_t s)
+void gsr_launch_duplicate_keys(GsrGeometry g, int P, int W, void* keys, int key_bytes, uint32_t* vals, uint32_t* clear, size_t clear_words, hipStream_t s)
 {
 	const int nb = (P + GSR_PREPROCESS_BLOCK - 1) / GSR_PREPROCESS_BLOCK;
 	hipLaunchKernelGGL(gsr_duplicate_keys_kernel, dim3(nb), dim3(GSR_PREPROCESS_BLOCK), 0, s, g, P, (uint32_t)gsr_grid_x(W),
-	                   keys, vals, clear, clear_words);
+	                   keys, key_bytes, vals, clear, clear_words);
 }
 
 // ---- tile ranges (rasterizer_impl.cu:133-159; ranges zeroed first, :377) -------------------------
@@ -181,16 +184,22 @@ void gsr_launch_duplicate_keys(GsrGeometry g, int P, int W, uint32_t* keys, uint
 // zeroes the whole array first, rasterizer_impl.cu:377): every element of `ranges` is written exactly once.
 // Also clears the per-instance validity bytes of the backward pass (`valid`, one byte per instance = one
 // dword per thread here): they live in the sort's ping-pong buffer, which is dead once the sort has finished.
-__global__ void __launch_bounds__(256) gsr_tile_ranges_kernel(const uint32_t* __restrict__ tile_keys, int64_t L, uint2* ranges,
+template <typename KeyT>
+__global__ void __launch_bounds__(256) gsr_tile_ranges_kernel(const KeyT* __restrict__ tile_keys, int64_t L, uint2* ranges,
                                                               uint32_t ntiles, uint32_t* __restrict__ valid)
 {
 	const int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
 	if (i0 >= L) return;
 	valid[i0 >> 2] = 0u;
 	uint32_t k[4];
-	if (i0 + 3 < L) {
-		const uint4 v = *reinterpret_cast<const uint4*>(tile_keys + i0);  // the array is 256-byte aligned inside the blob
-		k[0] = v.x; k[1] = v.y; k[2] = v.z; k[3] = v.w;
+	if (i0 + 3 < L) {  // the array is 256-byte aligned inside the blob
+		if constexpr (sizeof(KeyT) == 4) {
+			const uint4 v = *reinterpret_cast<const uint4*>(tile_keys + i0);
+			k[0] = v.x; k[1] = v.y; k[2] = v.z; k[3] = v.w;
+		} else {
+			const uint2 v = *reinterpret_cast<const uint2*>(tile_keys + i0);
+			k[0] = v.x & 0xffffu; k[1] = v.x >> 16; k[2] = v.y & 0xffffu; k[3] = v.y >> 16;
+		}
 	} else {
 #pragma unroll
 		for (int j = 0; j < 4; j++) k[j] = (i0 + j < L) ? tile_keys[i0 + j] : 0u;
@@ -307,11 +316,14 @@ void gsr_launch_tile_order(GsrImage img, int ntiles, bool backward, hipStream_t 
 	hipLaunchKernelGGL(gsr_tile_order_kernel, dim3(1), dim3(1024), 0, s, ranges, key, (uint32_t)ntiles, img.tile_order);
 }
 
-void gsr_launch_tile_ranges(const uint32_t* tile_keys, int64_t R, uint2* ranges, int ntiles, uint32_t* valid, hipStream_t s)
+void gsr_launch_tile_ranges(const void* tile_keys, int key_bytes, int64_t R, uint2* ranges, int ntiles, uint32_t* valid, hipStream_t s)
 {
-	if (R > 0)
-		hipLaunchKernelGGL(gsr_tile_ranges_kernel, dim3((unsigned)((R + 1023) / 1024)), dim3(256), 0, s, tile_keys, R, ranges,
-		                   (uint32_t)ntiles, valid);
+	if (R > 0 && key_bytes == 2)
+		hipLaunchKernelGGL(gsr_tile_ranges_kernel<uint16_t>, dim3((unsigned)((R + 1023) / 1024)), dim3(256), 0, s, (const uint16_t*)tile_keys, R,
+		                   ranges, (uint32_t)ntiles, valid);
+	else if (R > 0)
+		hipLaunchKernelGGL(gsr_tile_ranges_kernel<uint32_t>, dim3((unsigned)((R + 1023) / 1024)), dim3(256), 0, s, (const uint32_t*)tile_keys, R,
+		                   ranges, (uint32_t)ntiles, valid);
 	else
 		(void)hipMemsetAsync(ranges, 0, (size_t)ntiles * sizeof(uint2), s);
 }

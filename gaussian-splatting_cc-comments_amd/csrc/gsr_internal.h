@@ -108,18 +108,21 @@ void gsr_launch_mark_visible(int P, const float* means3D, const float* viewmatri
 
 // binning.hip
 void gsr_launch_sorted_block_sums(GsrGeometry g, int P, int result_in_alt, hipStream_t s);
-void gsr_launch_duplicate_keys(GsrGeometry g, int P, int W, uint32_t* keys, uint32_t* vals, uint32_t* clear, size_t clear_words, hipStream_t s);
-void gsr_launch_tile_ranges(const uint32_t* tile_keys, int64_t R, uint2* ranges, int ntiles, uint32_t* valid, hipStream_t s);
+void gsr_launch_duplicate_keys(GsrGeometry g, int P, int W, void* keys, int key_bytes, uint32_t* vals, uint32_t* clear, size_t clear_words, hipStream_t s);
+void gsr_launch_tile_ranges(const void* tile_keys, int key_bytes, int64_t R, uint2* ranges, int ntiles, uint32_t* valid, hipStream_t s);
 void gsr_launch_tile_order(GsrImage img, int ntiles, bool backward, hipStream_t s);
 
 // sort.hip
 int gsr_radix_num_passes(int nbits_total);
 size_t gsr_radix_table_bytes(size_t n);
 size_t gsr_radix_clear_words(size_t n);  // leading words of the table that the producer of the keys must zero
-void gsr_radix_sort_passes(uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v1, size_t n, int nbits_total, int npass_total,
-                           int pass_first, int pass_count, void* table_mem, const uint32_t* bias, hipStream_t s);
-void gsr_radix_sort_u32(uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v1, size_t n, int nbits_total, void* table_mem,
-                        int* result_in_first, int clear_table, hipStream_t s);
+void gsr_radix_sort_passes(void* k0, uint32_t* v0, void* k1, uint32_t* v1, size_t n, int nbits_total, int npass_total,
+                           int pass_first, int pass_count, void* table_mem, const uint32_t* bias, int key_bytes, hipStream_t s);
+void gsr_radix_sort_u32(void* k0, uint32_t* v0, void* k1, uint32_t* v1, size_t n, int nbits_total, void* table_mem,
+                        int* result_in_first, int clear_table, int key_bytes, hipStream_t s);
+// bytes per tile key of an instance-sized sort: 2 when every tile id fits 16 bits AND the sort runs the instance-sized
+// kernels (sort.hip), else 4
+int gsr_tile_key_bytes(int ntiles, size_t num_rendered);
 
 // render_forward.hip
 void gsr_launch_render_forward(int W, int H, GsrImage img, const uint32_t* point_list, const GsrSplat* splat,

@@ -263,7 +263,7 @@ void gsr_launch_knn(int P, const float* points, float* mean_dist2, void* scratch
 	hipLaunchKernelGGL(gsr_knn_bounds_final_kernel, dim3(1), dim3(64), 0, s, np, k.partial, k.bounds);
 	hipLaunchKernelGGL(gsr_knn_morton_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, points, k.bounds, k.codes, k.idx);
 	int in_first = 1;
-	gsr_radix_sort_u32(k.codes, k.idx, k.codes_alt, k.idx_alt, (size_t)P, 30, k.table, &in_first, 1, s);
+	gsr_radix_sort_u32(k.codes, k.idx, k.codes_alt, k.idx_alt, (size_t)P, 30, k.table, &in_first, 1, 4, s);
 	const uint32_t* order = in_first ? k.idx : k.idx_alt;
 	hipLaunchKernelGGL(gsr_knn_gather_kernel, dim3(nb), dim3(GSR_KNN_BOX), 0, s, P, points, order, k.sorted, k.boxes);
 	hipLaunchKernelGGL(gsr_knn_super_kernel, dim3((ns + 255) / 256), dim3(256), 0, s, nb, ns, k.boxes, k.supers);

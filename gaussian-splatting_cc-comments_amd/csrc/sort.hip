@@ -77,8 +77,8 @@ __device__ __forceinline__ size_t gsr_sort_index(int block, int wave, int it, in
 	return (size_t)block * (GSR_SORT_THREADS * ITEMS) + (size_t)wave * (64 * ITEMS) + (size_t)it * 64 + lane;
 }
 
-template <int ITEMS>
-__global__ void __launch_bounds__(GSR_SORT_THREADS) gsr_radix_hist_kernel(const uint32_t* __restrict__ keys, size_t n,
+template <int ITEMS, typename KeyT>
+__global__ void __launch_bounds__(GSR_SORT_THREADS) gsr_radix_hist_kernel(const KeyT* __restrict__ keys, size_t n,
                                                                           int shift, uint32_t mask,
                                                                           uint32_t* __restrict__ table, int nblocks,
                                                                           uint32_t* __restrict__ chunk_sums, int nchunks,
@@ -90,27 +90,36 @@ __global__ void __launch_bounds__(GSR_SORT_THREADS) gsr_radix_hist_kernel(const 
 	const GsrKeyBias kb = gsr_sort_bias(bias, s_bias);
 	const bool biased = bias != nullptr;
 	__syncthreads();
-	// the histogram does not care which thread counts which element of the block's tile: 16-byte loads
+	// the histogram does not care which thread counts which element of the block's tile: 16-byte loads (4 keys of 32 bits or
+	// 8 keys of 16 bits each)
 	constexpr int TILE = GSR_SORT_THREADS * ITEMS;
+	constexpr int KPV = 16 / (int)sizeof(KeyT), NV = ITEMS / KPV;
+	static_assert(NV >= 1 && NV * KPV == ITEMS, "a thread's keys must fill whole 16-byte loads");
 	const size_t first = (size_t)blockIdx.x * TILE;
 	if (first + TILE <= n) {
 		const uint4* src = reinterpret_cast<const uint4*>(keys + first);  // tile starts are multiples of 1024 elements
-		uint4 v[ITEMS / 4];
+		uint4 v[NV];
 #pragma unroll
-		for (int it = 0; it < ITEMS / 4; it++) v[it] = src[it * GSR_SORT_THREADS + threadIdx.x];
+		for (int it = 0; it < NV; it++) v[it] = src[it * GSR_SORT_THREADS + threadIdx.x];
 #pragma unroll
-		for (int it = 0; it < ITEMS / 4; it++) {
-			atomicAdd(&hist[(gsr_sort_key(v[it].x, kb, biased) >> shift) & mask], 1u);
-			atomicAdd(&hist[(gsr_sort_key(v[it].y, kb, biased) >> shift) & mask], 1u);
-			atomicAdd(&hist[(gsr_sort_key(v[it].z, kb, biased) >> shift) & mask], 1u);
-			atomicAdd(&hist[(gsr_sort_key(v[it].w, kb, biased) >> shift) & mask], 1u);
+		for (int it = 0; it < NV; it++) {
+			const uint32_t w[4] = {v[it].x, v[it].y, v[it].z, v[it].w};
+#pragma unroll
+			for (int c = 0; c < 4; c++) {
+				if constexpr (sizeof(KeyT) == 4) {
+					atomicAdd(&hist[(gsr_sort_key(w[c], kb, biased) >> shift) & mask], 1u);
+				} else {
+					atomicAdd(&hist[((w[c] & 0xffffu) >> shift) & mask], 1u);
+					atomicAdd(&hist[((w[c] >> 16) >> shift) & mask], 1u);
+				}
+			}
 		}
 	} else {
 		const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll
 		for (int it = 0; it < ITEMS; it++) {
 			const size_t i = gsr_sort_index<ITEMS>(blockIdx.x, wave, it, lane);
-			if (i < n) atomicAdd(&hist[(gsr_sort_key(keys[i], kb, biased) >> shift) & mask], 1u);
+			if (i < n) atomicAdd(&hist[(gsr_sort_key((uint32_t)keys[i], kb, biased) >> shift) & mask], 1u);
 		}
 	}
 	__syncthreads();
@@ -125,9 +134,9 @@ __global__ void __launch_bounds__(GSR_SORT_THREADS) gsr_radix_hist_kernel(const 
 	}
 }
 
-template <int ITEMS>
+template <int ITEMS, typename KeyT>
 __global__ void __launch_bounds__(GSR_SORT_THREADS) gsr_radix_scatter_kernel(
-	const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, uint32_t* __restrict__ keys_out,
+	const KeyT* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, KeyT* __restrict__ keys_out,
 	uint32_t* __restrict__ vals_out, size_t n, int shift, int nbits, const uint32_t* __restrict__ table, int nblocks,
 	const uint32_t* __restrict__ chunk_sums, int nchunks, const uint32_t* __restrict__ bias)
 {
@@ -135,10 +144,11 @@ __global__ void __launch_bounds__(GSR_SORT_THREADS) gsr_radix_scatter_kernel(
 	__shared__ uint32_t gofs[GSR_SORT_RADIX];                           // global base of a digit minus its local base
 	__shared__ uint32_t wsum[GSR_SORT_THREADS / 64];
 	constexpr int TILE = GSR_SORT_THREADS * ITEMS;
-	__shared__ __attribute__((aligned(16))) uint32_t sstage[2 * TILE];  // the block's elements in digit order; before that, the offset walk's partial sums
-	static_assert(2 * TILE >= 2 * (GSR_SORT_THREADS / 64) * GSR_SORT_RADIX, "the walk's partial sums and the ranking's peer masks must fit the staging area");
-	uint32_t* const skey = sstage;
-	uint32_t* const sval = sstage + TILE;
+	constexpr int KEY_WORDS = TILE * (int)sizeof(KeyT) / 4;
+	__shared__ __attribute__((aligned(16))) uint32_t sstage[KEY_WORDS + TILE];  // the block's elements in digit order; before that, the offset walk's partial sums
+	static_assert(KEY_WORDS + TILE >= 2 * (GSR_SORT_THREADS / 64) * GSR_SORT_RADIX, "the walk's partial sums and the ranking's peer masks must fit the staging area");
+	KeyT* const skey = reinterpret_cast<KeyT*>(sstage);
+	uint32_t* const sval = sstage + KEY_WORDS;
 	__shared__ uint32_t s_bias[2];
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	const uint32_t mask = (1u << nbits) - 1u;
@@ -153,7 +163,7 @@ __global__ void __launch_bounds__(GSR_SORT_THREADS) gsr_radix_scatter_kernel(
 	for (int it = 0; it < ITEMS; it++) {
 		const size_t i = gsr_sort_index<ITEMS>(blockIdx.x, wave, it, lane);
 		const bool valid = i < n;
-		key[it] = valid ? keys_in[i] : 0u;
+		key[it] = valid ? (uint32_t)keys_in[i] : 0u;
 		val[it] = valid ? vals_in[i] : 0u;
 	}
 
@@ -340,8 +350,8 @@ __global__ void __launch_bounds__(GSR_SORT_THREADS) gsr_radix_scatter_kernel(
 	const size_t first = (size_t)blockIdx.x * TILE;
 	const uint32_t count = (uint32_t)((n - first < (size_t)TILE) ? (n - first) : (size_t)TILE);
 	for (uint32_t i = threadIdx.x; i < count; i += GSR_SORT_THREADS) {
-		const uint32_t k = skey[i];
-		const uint32_t dst = gofs[(gsr_sort_key(k, kb, biased) >> shift) & mask] + i;
+		const KeyT k = skey[i];
+		const uint32_t dst = gofs[(gsr_sort_key((uint32_t)k, kb, biased) >> shift) & mask] + i;
 		if (dst < n) {  // always true for consistent tables; a corrupted table must not turn into a wild store
 			keys_out[dst] = k;
 			vals_out[dst] = sval[i];
@@ -350,6 +360,12 @@ __global__ void __launch_bounds__(GSR_SORT_THREADS) gsr_radix_scatter_kernel(
 }
 
 int gsr_radix_num_passes(int nbits_total) { return (nbits_total + 7) / 8; }
+
+int gsr_tile_key_bytes(int ntiles, size_t num_rendered)
+{
+	(void)num_rendered;
+	return ntiles <= 65536 ? 2 : 4;
+}
 
 static inline int gsr_sort_items(size_t n) { return n <= GSR_SORT_SMALL_N ? GSR_SORT_ITEMS_SMALL : (n < GSR_SORT_HUGE_N ? GSR_SORT_ITEMS_LARGE : GSR_SORT_ITEMS_HUGE); }
 static inline size_t gsr_sort_nblocks(size_t n) { const size_t tile = (size_t)GSR_SORT_THREADS * gsr_sort_items(n); return (n + tile - 1) / tile; }
@@ -366,39 +382,48 @@ size_t gsr_radix_table_bytes(size_t n)
 	return gsr_align_up((gsr_radix_clear_words(n) + gsr_sort_nblocks(n) * GSR_SORT_RADIX) * sizeof(uint32_t));
 }
 
-template <int ITEMS>
-static void gsr_radix_pass(const uint32_t* ki, const uint32_t* vi, uint32_t* ko, uint32_t* vo, size_t n, int shift, int bits,
+template <int ITEMS, typename KeyT>
+static void gsr_radix_pass(const KeyT* ki, const uint32_t* vi, KeyT* ko, uint32_t* vo, size_t n, int shift, int bits,
                            uint32_t* table, uint32_t* chunk_sums, int nchunks, const uint32_t* bias, hipStream_t s)
 {
 	const int nblocks = (int)((n + (size_t)GSR_SORT_THREADS * ITEMS - 1) / ((size_t)GSR_SORT_THREADS * ITEMS));
 	const uint32_t mask = (1u << bits) - 1u;
-	hipLaunchKernelGGL(gsr_radix_hist_kernel<ITEMS>, dim3(nblocks), dim3(GSR_SORT_THREADS), 0, s, ki, n, shift, mask, table, nblocks,
+	hipLaunchKernelGGL((gsr_radix_hist_kernel<ITEMS, KeyT>), dim3(nblocks), dim3(GSR_SORT_THREADS), 0, s, ki, n, shift, mask, table, nblocks,
 	                   chunk_sums, nchunks, bias);
-	hipLaunchKernelGGL(gsr_radix_scatter_kernel<ITEMS>, dim3(nblocks), dim3(GSR_SORT_THREADS), 0, s, ki, vi, ko, vo, n, shift, bits,
+	hipLaunchKernelGGL((gsr_radix_scatter_kernel<ITEMS, KeyT>), dim3(nblocks), dim3(GSR_SORT_THREADS), 0, s, ki, vi, ko, vo, n, shift, bits,
 	                   table, nblocks, chunk_sums, nchunks, bias);
 }
 
 // Runs passes [pass_first, pass_first + pass_count) of the LSD sort on key bits [0, nbits_total) (spread evenly over
 // npass_total passes).  Pass p reads (k0,v0) when p is even and (k1,v1) when odd and writes the other pair; the chunk sums
 // in table_mem must be zero (each pass uses its own slice).  bias: NULL, or the 128 partial maxima of gsr_sort_bias().
-void gsr_radix_sort_passes(uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v1, size_t n, int nbits_total, int npass_total,
-                           int pass_first, int pass_count, void* table_mem, const uint32_t* bias, hipStream_t s)
+// key_bytes: 4, or 2 = the keys are uint16_t (instance-sized sorts of tile ids below 65 536: a quarter less traffic per pass).
+void gsr_radix_sort_passes(void* k0, uint32_t* v0, void* k1, uint32_t* v1, size_t n, int nbits_total, int npass_total,
+                           int pass_first, int pass_count, void* table_mem, const uint32_t* bias, int key_bytes, hipStream_t s)
 {
 	if (n == 0) return;
-	const int items = gsr_sort_items(n);
-	const int nchunks = (int)gsr_sort_nchunks(n);
+	// 16-bit keys: 8 per 16-byte load, so the small sorts take 8 items per thread instead of 4 (fewer blocks than the table
+	// and the cleared chunk sums were sized for: both stay inside their areas)
+	const int items = (key_bytes == 2 && gsr_sort_items(n) == GSR_SORT_ITEMS_SMALL) ? 8 : gsr_sort_items(n);
+	const size_t nblocks_ = (n + (size_t)GSR_SORT_THREADS * items - 1) / ((size_t)GSR_SORT_THREADS * items);
+	const int nchunks = (int)((nblocks_ + GSR_SORT_CHUNK - 1) / GSR_SORT_CHUNK);
+	const int nsuper = (nchunks + GSR_SORT_CHUNK - 1) / GSR_SORT_CHUNK;
 	uint32_t* chunk_base = (uint32_t*)table_mem;
 	uint32_t* table = chunk_base + gsr_radix_clear_words(n);
 	int shift = 0;
 	for (int p = 0; p < npass_total && p < pass_first + pass_count; p++) {
 		const int bits = (nbits_total - shift + (npass_total - p) - 1) / (npass_total - p);  // spread bits evenly over passes
 		if (p >= pass_first) {
-			uint32_t *ki = (p % 2 == 0) ? k0 : k1, *vi = (p % 2 == 0) ? v0 : v1;
-			uint32_t *ko = (p % 2 == 0) ? k1 : k0, *vo = (p % 2 == 0) ? v1 : v0;
-			uint32_t* cs = chunk_base + (size_t)p * GSR_SORT_RADIX * (nchunks + (int)gsr_sort_nsuper(n));
-			if (items == GSR_SORT_ITEMS_SMALL) gsr_radix_pass<GSR_SORT_ITEMS_SMALL>(ki, vi, ko, vo, n, shift, bits, table, cs, nchunks, bias, s);
-			else if (items == GSR_SORT_ITEMS_LARGE) gsr_radix_pass<GSR_SORT_ITEMS_LARGE>(ki, vi, ko, vo, n, shift, bits, table, cs, nchunks, bias, s);
-			else gsr_radix_pass<GSR_SORT_ITEMS_HUGE>(ki, vi, ko, vo, n, shift, bits, table, cs, nchunks, bias, s);
+			void *ki = (p % 2 == 0) ? k0 : k1, *ko = (p % 2 == 0) ? k1 : k0;
+			uint32_t *vi = (p % 2 == 0) ? v0 : v1, *vo = (p % 2 == 0) ? v1 : v0;
+			uint32_t* cs = chunk_base + (size_t)p * GSR_SORT_RADIX * (nchunks + nsuper);
+			if (key_bytes == 2) {
+				if (items == 8) gsr_radix_pass<8, uint16_t>((const uint16_t*)ki, vi, (uint16_t*)ko, vo, n, shift, bits, table, cs, nchunks, bias, s);
+				else if (items == GSR_SORT_ITEMS_LARGE) gsr_radix_pass<GSR_SORT_ITEMS_LARGE, uint16_t>((const uint16_t*)ki, vi, (uint16_t*)ko, vo, n, shift, bits, table, cs, nchunks, bias, s);
+				else gsr_radix_pass<GSR_SORT_ITEMS_HUGE, uint16_t>((const uint16_t*)ki, vi, (uint16_t*)ko, vo, n, shift, bits, table, cs, nchunks, bias, s);
+			} else if (items == GSR_SORT_ITEMS_SMALL) gsr_radix_pass<GSR_SORT_ITEMS_SMALL, uint32_t>((const uint32_t*)ki, vi, (uint32_t*)ko, vo, n, shift, bits, table, cs, nchunks, bias, s);
+			else if (items == GSR_SORT_ITEMS_LARGE) gsr_radix_pass<GSR_SORT_ITEMS_LARGE, uint32_t>((const uint32_t*)ki, vi, (uint32_t*)ko, vo, n, shift, bits, table, cs, nchunks, bias, s);
+			else gsr_radix_pass<GSR_SORT_ITEMS_HUGE, uint32_t>((const uint32_t*)ki, vi, (uint32_t*)ko, vo, n, shift, bits, table, cs, nchunks, bias, s);
 		}
 		shift += bits;
 	}
@@ -407,12 +432,12 @@ void gsr_radix_sort_passes(uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v
 // Sorts on key bits [0, nbits_total).  Ping-pongs between (k0,v0) and (k1,v1); the sorted result
 // ends in (k0,v0) when the pass count is even and in (k1,v1) when odd -- returned through *in_first.
 // clear_table: zero the chunk sums here (a memset on the stream); 0 when the kernel that produced the keys already did.
-void gsr_radix_sort_u32(uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v1, size_t n, int nbits_total, void* table_mem,
-                        int* result_in_first, int clear_table, hipStream_t s)
+void gsr_radix_sort_u32(void* k0, uint32_t* v0, void* k1, uint32_t* v1, size_t n, int nbits_total, void* table_mem,
+                        int* result_in_first, int clear_table, int key_bytes, hipStream_t s)
 {
 	const int npass = gsr_radix_num_passes(nbits_total);
 	*result_in_first = (npass % 2 == 0) ? 1 : 0;
 	if (n == 0 || npass == 0) { *result_in_first = 1; return; }
 	if (clear_table) (void)hipMemsetAsync(table_mem, 0, gsr_radix_clear_words(n) * sizeof(uint32_t), s);
-	gsr_radix_sort_passes(k0, v0, k1, v1, n, nbits_total, npass, 0, npass, table_mem, nullptr, s);
+	gsr_radix_sort_passes(k0, v0, k1, v1, n, nbits_total, npass, 0, npass, table_mem, nullptr, key_bytes, s);
 }

@@ -37,7 +37,7 @@ class ImageLayout(ctypes.Structure):
 
 class BinningLayout(ctypes.Structure):
     _fields_ = [(n, _sz) for n in ("point_list", "point_list_alt", "tile_keys", "tile_keys_alt", "sort_table",
-                                   "total")]
+                                   "total", "tile_key_bytes")]
 
 
 class KernelTime(ctypes.Structure):

@@ -99,10 +99,11 @@ typedef struct {
 typedef struct {
 	size_t point_list;     /* [R] u32 Gaussian ids sorted by (tile, depth, id) -- the reference's point_list */
 	size_t point_list_alt; /* [R] u32 sort ping-pong */
-	size_t tile_keys;      /* [R] u32 tile id of each sorted instance (the high word of the reference's key) */
-	size_t tile_keys_alt;  /* [R] u32 sort ping-pong; after the forward its first R bytes are the backward's slot validity flags */
+	size_t tile_keys;      /* [R] tile id of each sorted instance (the high word of the reference's key), tile_key_bytes each */
+	size_t tile_keys_alt;  /* [R] sort ping-pong; after the forward its first R bytes are the backward's slot validity flags */
 	size_t sort_table;     /* radix histogram table of the tile sort */
 	size_t total;
+	size_t tile_key_bytes; /* 2 (uint16_t: every tile id of the image is below 65 536) or 4 (uint32_t); both arrays are sized for 4 */
 } gsr_binning_layout;
 
 int gsr_geometry_layout_of(int P, gsr_geometry_layout* out);

@@ -207,7 +207,8 @@ def _properties(name, check_linearity=True):
     tiles_touched = u32(cap["geom"], gl.tiles_touched, P).to(torch.int64)
     assert int(tiles_touched.sum()) == R
     assert torch.equal(tiles_touched > 0, radii > 0)
-    tile_keys = u32(cap["binning"], bl.tile_keys, R).to(torch.int64)
+    kb = int(bl.tile_key_bytes)
+    tile_keys = cap["binning"][bl.tile_keys:bl.tile_keys + kb * R].view(torch.int16 if kb == 2 else torch.int32).to(torch.int64) & (0xFFFF if kb == 2 else 0xFFFFFFFF)
     plist = u32(cap["binning"], bl.point_list, R).to(torch.int64)
     assert bool((tile_keys[1:] >= tile_keys[:-1]).all()), "instances sorted by tile"
     assert int(tile_keys.max()) < T

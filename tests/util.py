@@ -143,7 +143,8 @@ def unpack_state(cap, P, W, H):
     if R > 0:
         bl = _C.binning_layout(P, R, W, H)
         o["point_list"] = binning[bl.point_list:bl.point_list + 4 * R].view(np.uint32)
-        o["tile_keys"] = binning[bl.tile_keys:bl.tile_keys + 4 * R].view(np.uint32)
+        kb = int(bl.tile_key_bytes)   # 2: uint16 tile ids (every id of the image < 65 536), 4: uint32
+        o["tile_keys"] = binning[bl.tile_keys:bl.tile_keys + kb * R].view(np.uint16 if kb == 2 else np.uint32).astype(np.uint32)
         # the reference's 64-bit key of every sorted instance: tile id << 32 | depth bits
         o["keys"] = (o["tile_keys"].astype(np.uint64) << np.uint64(32)) | depth_bits[o["point_list"]].astype(np.uint64)
     return o
