@@ -15,14 +15,20 @@ last = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 rows = []
 for r in csv.DictReader(open(path)):
     name = r["Kernel_Name"].split("(")[0].replace("void ", "")
-    rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), name))
+    if name.startswith("gsr_") or "rocclr" in name:   # the library's kernels and the runtime's copy / fill kernels between them
+        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), name))
 rows.sort()
 starts = [i for i, r in enumerate(rows) if r[2].startswith("gsr_preprocess_kernel")]
 steps = [rows[a:b] for a, b in zip(starts[:-1], starts[1:])]
 # keep the steps of the most common length (the timed ones; per-kernel-table steps run the colour kernel in line)
+steps = [[r for r in s if not (r[2].startswith("__amd_rocclr_fill") and r is s[-1])] for s in steps]   # the next step's status memset
 steps = [s for s in steps if s and s[-1][2].startswith("gsr_gaussian_backward")]
 n = statistics.mode(len(s) for s in steps)
-steps = [s for s in steps if len(s) == n][-last:]
+steps = [s for s in steps if len(s) == n]
+# the timed steps run the colour kernel on the helper stream beside the geometry kernel; the steps of bench.py's per-kernel
+# table run it in line and drain the queue around every stage (event records): prefer the former
+beside = [s for s in steps if any(r[2].startswith("gsr_preprocess_color") and r[0] < s[0][1] for r in s[1:3])]
+steps = (beside or steps)[-last:]
 print(f"{len(steps)} steps of {n} dispatches each")
 print(f"{'#':>2} {'kernel':44s} {'start us':>9} {'dur us':>8} {'gap us':>7}")
 tot_gap = tot_busy = 0.0
