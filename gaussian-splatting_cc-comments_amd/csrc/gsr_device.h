@@ -21,17 +21,20 @@ __device__ static const float GSR_SH_C3[7] = {-0.5900435899266435f, 2.8906114426
                                               0.3731763325901154f,  -0.4570457994644658f, 1.445305721320277f,
                                               -0.5900435899266435f};
 
-// One 48-byte record per Gaussian: everything the blend kernels gather per (Gaussian, tile)
-// instance, so a batch load is three 16-byte reads of one contiguous record.
+// One 48-byte record per Gaussian: everything the blend kernels gather per (Gaussian, tile) instance, so a batch load is three
+// 16-byte reads of one contiguous record.  Two kernels fill it -- the geometry kernel the first 32 bytes (two 16-byte stores),
+// the SH colour kernel (helper stream) the last 16 (one store).  Round 2 had the colour at words 6..8: its 8 + 4-byte stores into
+// lines the other kernel was writing cost 1.74x the bytes (85 MB written for 49).  Measured alternative, not kept: colour in a
+// dense array of its own writes the minimum (53 MB) but every gathered 16-byte colour record then costs the blend kernels a
+// line of its own (forward 393 -> 629 MB, backward 960 -> 1 237 MB of fabric traffic, both 1 % slower).
 struct __attribute__((aligned(16))) GsrSplat {
 	float x, y;           // pixel-space mean (forward.cu:294)
 	float ca, cb;         // conic a, b
 	float cc, opacity;    // conic c, opacity (forward.cu:320)
-	float r, g;           // colour
-	float b;
-	uint32_t unused;      // (the first gradient slot of the Gaussian lives in the dense GsrGeometry::slot_base array)
 	uint32_t rect_min;    // tile rect min: x | y << 16
 	uint32_t rect_wh;     // tile rect size: w | h << 16
+	float r, g, b;        // colour (SH colour clamped at 0, or colors_precomp)
+	uint32_t unused;
 };
 static_assert(sizeof(GsrSplat) == 48, "splat record must be 48 bytes");
 

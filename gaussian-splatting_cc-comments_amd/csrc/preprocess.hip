@@ -38,7 +38,7 @@ __device__ __forceinline__ float gsr_sh_channel(int deg, const float* sh, int ch
 //                                (44 B in, 56 B out per Gaussian; the depth sort and the instance count wait for it)
 //   gsr_preprocess_color_kernel  view-dependent colour from the SH rows (204 B in, 49 B out): needed by nothing before the
 //                                blend, so api.hip runs it on a helper stream beside the geometry kernel and the depth sort
-// Both write disjoint fields of the 48-byte splat record.  Precomputed colours need no second kernel.
+// Both write disjoint 16-byte-aligned parts of the 48-byte splat record.  Precomputed colours need no second kernel.
 //
 // LEAF: the inputs are the optimiser's raw leaves (gsr_internal.h); activations happen here.
 template <bool LEAF>
@@ -114,14 +114,12 @@ __global__ void __launch_bounds__(GSR_PREPROCESS_BLOCK) gsr_preprocess_kernel(Gs
 			radius_out = gsr_f2i(my_radius);
 			depth_key = __float_as_uint(p_view.z);  // > 0.2, so unsigned order == float order
 			rect = make_uint2((uint32_t)minx | ((uint32_t)miny << 16), (uint32_t)(maxx - minx) | ((uint32_t)(maxy - miny) << 16));
-			// the record's fields other than the colour (GsrSplat: x, y, conic a, b | conic c, opacity, r, g | b, -, rect)
-			float* rec = reinterpret_cast<float*>(a.g.splat + idx);
-			*reinterpret_cast<float4*>(rec) = make_float4(pix, piy, conic_a, conic_b);
-			*reinterpret_cast<float2*>(rec + 4) = make_float2(conic_c, LEAF ? gsr_act_sigmoid(opac) : opac);
-			*reinterpret_cast<float2*>(rec + 10) = make_float2(__uint_as_float(rect.x), __uint_as_float(rect.y));
+			// the geometry part of the record (GsrSplat: x, y, conic a, b | conic c, opacity, rect | colour): two 16-byte stores, 32 contiguous bytes
+			float4* rec = reinterpret_cast<float4*>(a.g.splat + idx);
+			rec[0] = make_float4(pix, piy, conic_a, conic_b);
+			rec[1] = make_float4(conic_c, LEAF ? gsr_act_sigmoid(opac) : opac, __uint_as_float(rect.x), __uint_as_float(rect.y));
 			if (a.colors_precomp) {
-				*reinterpret_cast<float2*>(rec + 6) = make_float2(col_in[0], col_in[1]);
-				rec[8] = col_in[2];
+				rec[2] = make_float4(col_in[0], col_in[1], col_in[2], 0.f);
 				a.g.clamped[idx] = 0;
 			}
 		} while (0);
@@ -241,9 +239,7 @@ __global__ void __launch_bounds__(GSR_PREPROCESS_BLOCK) gsr_preprocess_color_ker
 		rgb[ch] = fmaxf(v, 0.0f);
 	}
 	a.g.clamped[idx] = clamp_bits;
-	float* rec = reinterpret_cast<float*>(a.g.splat + idx);
-	*reinterpret_cast<float2*>(rec + 6) = make_float2(rgb[0], rgb[1]);
-	rec[8] = rgb[2];
+	reinterpret_cast<float4*>(a.g.splat + idx)[2] = make_float4(rgb[0], rgb[1], rgb[2], 0.f);   // the record's last 16 bytes: one aligned store per lane
 }
 
 void gsr_launch_preprocess(const GsrPreprocessArgs& a, hipStream_t s)

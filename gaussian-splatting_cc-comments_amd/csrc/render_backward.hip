@@ -129,15 +129,15 @@ __global__ void __launch_bounds__(64 * GSR_WAVES_PER_WG) __attribute__((amdgpu_w
 		GSR_TILE_STAT(st_staged += (unsigned)cnt;)
 		if (keep) {
 			const int pos = gsr_mbcnt(mask);
-			const uint32_t rmin = __float_as_uint(rc.z), rwh = __float_as_uint(rc.w);
+			const uint32_t rmin = __float_as_uint(rb.z), rwh = __float_as_uint(rb.w);
 			const uint32_t slot = sbase + ((uint32_t)ty - (rmin >> 16)) * (rwh & 0xffffu) + ((uint32_t)tx - (rmin & 0xffffu));
 			rec[0][pos] = make_float4(ra.x, ra.x, ra.y, ra.y);  // mean x, y
 			// conic a and c pre-multiplied by -0.5: a power of two commutes with every rounding of `power`, so its bits are the
 			// forward's (gsr_pair_power_halved) with one packed multiply less per pair; the epilogue undoes it inside an FMA
 			rec[1][pos] = make_float4(-0.5f * ra.z, -0.5f * ra.z, ra.w, ra.w);  // -0.5 conic a, conic b
 			rec[2][pos] = make_float4(-0.5f * rb.x, -0.5f * rb.x, rb.y, rb.y);  // -0.5 conic c, opacity
-			rec[3][pos] = make_float4(rb.z, rb.z, rb.w, rb.w);  // r, g
-			rec[4][pos] = make_float4(rc.x, rc.x, __int_as_float(n - 1 - (base + lane)), __uint_as_float(slot));  // b, position in the full range, slot
+			rec[3][pos] = make_float4(rc.x, rc.x, rc.y, rc.y);  // r, g
+			rec[4][pos] = make_float4(rc.z, rc.z, __int_as_float(n - 1 - (base + lane)), __uint_as_float(slot));  // b, position in the full range, slot
 			recb[pos] = bands;
 		}
 		if (base + 64 + lane < n) {

@@ -67,7 +67,8 @@ __global__ void __launch_bounds__(64 * GSR_WAVES_PER_WG) gsr_render_forward_wave
 	// software pipeline: records one batch ahead, ids two batches ahead
 	float4 ra = make_float4(0, 0, 0, 0), rb = ra, rc = ra;
 	if (lane < n) {
-		const float4* p = reinterpret_cast<const float4*>(splat + plist[lane]);
+		const uint32_t id = plist[lane];
+		const float4* p = reinterpret_cast<const float4*>(splat + id);
 		ra = p[0]; rb = p[1]; rc = p[2];
 	}
 	uint32_t id_next = (64 + lane < n) ? plist[64 + lane] : 0u;
@@ -81,8 +82,8 @@ __global__ void __launch_bounds__(64 * GSR_WAVES_PER_WG) gsr_render_forward_wave
 		if (keep) {
 			const int pos = gsr_mbcnt(mask);
 			rec[0][pos] = make_float4(ra.x, ra.y, -0.5f * ra.z, ra.w);  // conic a, c pre-multiplied by -0.5 (exact)
-			rec[1][pos] = make_float4(-0.5f * rb.x, rb.y, rb.z, rb.w);
-			rec[2][pos] = make_float4(rc.x, __uint_as_float((uint32_t)(base + lane + 1)), __uint_as_float(bands), 0.f);
+			rec[1][pos] = make_float4(-0.5f * rb.x, rb.y, rc.x, rc.y);
+			rec[2][pos] = make_float4(rc.z, __uint_as_float((uint32_t)(base + lane + 1)), __uint_as_float(bands), 0.f);
 		}
 		if (base + 64 + lane < n) {
 			const float4* p = reinterpret_cast<const float4*>(splat + id_next);

@@ -69,7 +69,7 @@ size_t gsr_backward_scratch_bytes(int P, int64_t num_rendered);
 
 /* Byte offsets of the typed arrays inside each blob (introspection for tests / debuggers). */
 typedef struct {
-	size_t splat;          /* [P] 48-byte records: xy(2f) conic+opacity(4f) rgb(3f) slot_base(u32) rect_min(u16x2) rect_wh(u16x2) */
+	size_t splat;          /* [P] 48-byte records: xy(2f) conic a b c + opacity(4f) rect_min(u16x2) rect_wh(u16x2) rgb(3f) unused(u32) */
 	size_t depth_keys;     /* [P] u32: after the call, depth bits sorted ascending (culled = 0xFFFFFFFF last) -- in this array or in */
 	size_t depth_keys_alt; /* [P] u32 its ping-pong partner: status word 2 says which (1 = the _alt pair; three radix passes sufficed) */
 	size_t perm;           /* [P] u32 Gaussian ids in (depth, id) order (or in perm_alt, see above) */

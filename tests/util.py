@@ -117,10 +117,10 @@ def unpack_state(cap, P, W, H):
     geom, img, binning = cap["geom"].cpu().numpy(), cap["img"].cpu().numpy(), cap["binning"].cpu().numpy()
     gl, il = _C.geometry_layout(P), _C.image_layout(W, H)
     N, T = W * H, ((W + 15) // 16) * ((H + 15) // 16)
-    splat = geom[gl.splat:gl.splat + 48 * P].view(np.float32).reshape(P, 12)
+    splat = geom[gl.splat:gl.splat + 48 * P].view(np.float32).reshape(P, 12)    # x y | conic a b c opacity | rect (2 words) | r g b -
     o["means2D"] = splat[:, 0:2]
     o["conic_opacity"] = splat[:, 2:6]
-    o["rgb"] = splat[:, 6:9]
+    o["rgb"] = splat[:, 8:11]
     o["tiles_touched"] = geom[gl.tiles_touched:gl.tiles_touched + 4 * P].view(np.uint32)
     o["clamped_bits"] = geom[gl.clamped:gl.clamped + P]
     # depth sort outputs: Gaussian ids in (depth, id) order and their sorted depth bits
