@@ -31,9 +31,8 @@ import gsr_scene  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, corrected as
 # MI355X_MICROARCH.md "HBM" prescribes) of this same command, summarised by tools/pmc_summary.py
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r2_pmc_summary.json")
-if not os.path.exists(PMC_SUMMARY):
-    PMC_SUMMARY = os.path.join(ROOT, "profiles", "r1_pmc_summary.json")
+PMC_SUMMARY = next((f for f in (os.path.join(ROOT, "profiles", n) for n in ("r3_pmc_summary.json", "r2_pmc_summary.json", "r1_pmc_summary.json"))
+                    if os.path.exists(f)), os.path.join(ROOT, "profiles", "r3_pmc_summary.json"))
 KERNEL_SYMBOL = {"render_backward": "gsr_render_backward_wave_kernel", "render_forward": "gsr_render_forward_wave_kernel",
                  "gaussian_backward": "gsr_gaussian_backward_kernel", "preprocess": "gsr_preprocess_kernel",
                  "preprocess_color": "gsr_preprocess_color_kernel",
@@ -342,18 +341,21 @@ def step_stats(ms):
     return dict(min=round(ms[0], 4), median=round(med, 4), max=round(ms[-1], 4), n=n)
 
 
-def valu_issue_fraction(stage, workload):
-    """Fraction of the chip's VALU issue capacity the kernel used during its launch, from the committed PMC summary
-    (tools/profile_run.sh -> tools/pmc_summary.py): (4 * (SQ_INSTS_VALU - SQ_INSTS_VALU_TRANS_F32) + 8 * SQ_INSTS_VALU_TRANS_F32)
-    / (1024 SIMDs * SQ_BUSY_CYCLES / 32 shader engines).  Issue costs measured on MI355X with tools/valu_probe.hip
-    (profiles/r2_valu_probe.txt): one SIMD issues one wave64 VALU instruction per ~4 cycles whatever the number of resident
-    waves (fma, pk_fma, pk_mul, dpp, cndmask, cmp, max alike), a transcendental holds it for ~8.  Instruction counts and the
-    kernel's own cycle count come from the same PMC run, so no assumption about the clock enters."""
+def valu_issue_fraction(stage, workload, kernel_ms=None):
+    """Fraction of the chip's vector-ALU issue roof the kernel reaches, from the committed PMC summary (tools/profile_run.sh ->
+    tools/pmc_summary.py): roof time = sum over instruction classes of (count from SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F32 and
+    SQ_INSTS_VALU) x (the time one SIMD needs per instruction of the class, measured on this chip with tools/valu_probe.hip at
+    4-8 waves per SIMD -- profiles/r3_valu_probe.txt: plain adds / multiplies 1.1-1.2 ns, FMAs 1.6, compares / selects 1.85,
+    packed two-pixel ops 1.9-2.1, transcendentals 3.4), divided by 1024 SIMDs and by the kernel's duration.  Time-domain on both
+    sides, so no clock estimate enters; the counters were checked against kernels of known instruction counts
+    (profiles/r3_pmc_calibration.txt).  With kernel_ms given (this run's own duration of the kernel) the fraction is taken
+    against it, else against the duration recorded with the counters."""
     try:
         e = _pmc_entry(stage, workload)
-        return dict(frac=round(e["valu_issue_frac"], 3), clock_GHz=round(e["clock_GHz"], 3), valu_insts=int(e["SQ_INSTS_VALU"]),
-                    transcendental_insts=int(e.get("SQ_INSTS_VALU_TRANS_F32", 0)), cycles_per_inst=4.0,
-                    cycles_per_transcendental=8.0, simds=1024, avg_waves_per_simd=round(e.get("avg_waves_per_simd", 0.0), 2),
+        ms = kernel_ms if kernel_ms else e["kernel_ms"]
+        return dict(frac=round(e["valu_roof_ms"] / ms, 3), roof_ms=round(e["valu_roof_ms"], 4), kernel_ms=round(ms, 4),
+                    valu_insts=int(e["SQ_INSTS_VALU"]), class_counts={k: int(v) for k, v in e.get("valu_class_counts", {}).items()},
+                    avg_waves_per_simd=round(e.get("avg_waves_per_simd", 0.0), 2), model="per-class costs from tools/valu_probe.hip",
                     source=os.path.basename(PMC_SUMMARY))
     except (OSError, KeyError, ValueError, ZeroDivisionError):
         return None
@@ -648,10 +650,10 @@ def run_rank(args, rank, world, dev, phase=None):
         a = kern[dom]["GBps"] or 0.0
         roofline = dict(kernel=dom, bound="hbm", achieved=a, peak=HBM_PEAK_GBS, unit="GB/s",
                         frac=round(a / HBM_PEAK_GBS, 4), traffic=pmc_traffic(dom, args.config),
-                        valu_issue=valu_issue_fraction(dom, args.config),
-                        note="this kernel is bound by VALU issue, not by HBM (see valu_issue: share of the 1024 SIMDs' issue "
-                             "cycles its instructions occupy), so its HBM fraction is small by construction; 'kernels' "
-                             "lists the streaming stages with their own HBM fractions",
+                        valu_issue=valu_issue_fraction(dom, args.config, kern[dom]["ms"]),
+                        note="this kernel is bound by vector-ALU issue, not by HBM (see valu_issue: its instructions priced per class at "
+                             "the rates this chip sustains, against its duration), so its HBM fraction is small by construction; "
+                             "'kernels' lists the streaming stages with their own HBM fractions",
                         avg_launch_ms=kern[dom]["ms"], algorithmic_bytes_per_launch=kern[dom]["algorithmic_bytes"],
                         step_algorithmic_bytes=step_bytes,
                         step_GBps=round(step_bytes / (ms_per_step * 1e-3) / 1e9, 1),

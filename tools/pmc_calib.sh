@@ -10,6 +10,7 @@ export TMPDIR=/tmp
 cd /tmp
 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VALU_TRANS_F32 --output-format csv -d "$OUT/pmc" -- "$ROOT/tools/valu_probe" > "$OUT/probe_under_pmc.txt" 2>&1 || tail -3 "$OUT/probe_under_pmc.txt"
 rocprofv3 --pmc GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc_grbm" -- "$ROOT/tools/valu_probe" > "$OUT/probe_under_grbm.txt" 2>&1 || tail -3 "$OUT/probe_under_grbm.txt"
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_CVT --output-format csv -d "$OUT/pmc_class" -- "$ROOT/tools/valu_probe" > "$OUT/probe_under_class.txt" 2>&1 || tail -3 "$OUT/probe_under_class.txt"
 python3 - "$OUT" <<'PY'
 import csv, glob, sys, collections
 out = sys.argv[1]
@@ -33,6 +34,8 @@ with open(out + "/calibration.txt", "w") as o:
             line += f" {c['SQ_INSTS_VALU'] / max(known, 1):6.3f} | {c.get('SQ_ACTIVE_INST_VALU', 0) / max(c['SQ_INSTS_VALU'], 1):6.3f} | {c.get('SQ_BUSY_CYCLES', 0) / 32 / c['_dur_sq']:6.3f} | {4 * c.get('SQ_WAVE_CYCLES', 0) / max(waves, 1) / c['_dur_sq']:6.3f} |"
         if "GRBM_GUI_ACTIVE" in c:
             line += f" grbm {c['GRBM_GUI_ACTIVE'] / 8 / c['_dur_grbm']:6.3f}"
+        if "SQ_INSTS_VALU_MUL_F32" in c:   # which class counter an instruction kind lands in, per known instruction
+            line += " | class/known: " + " ".join(f"{n[14:]} {c.get(n, 0) / max(known, 1):.2f}" for n in ("SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_TRANS_F32", "SQ_INSTS_VALU_INT32", "SQ_INSTS_VALU_CVT"))
         print(line, file=o)
 print(open(out + "/calibration.txt").read())
 PY

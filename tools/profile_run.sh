@@ -20,7 +20,8 @@ n=0
 for counters in "FETCH_SIZE" "WRITE_SIZE" \
     "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" \
     "SQ_INSTS_VALU_TRANS_F32 SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_INSTS_SALU SQ_LDS_IDX_ACTIVE" \
-    "GRBM_GUI_ACTIVE"; do
+    "GRBM_GUI_ACTIVE" \
+    "SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_CVT SQ_INSTS_LDS_LOAD SQ_INSTS_LDS_STORE"; do
   rocprofv3 --pmc $counters --output-format csv -d "$OUT/pmc_$n" -- $BENCH > "$OUT/pmc_$n.log" 2>&1 || { tail -5 "$OUT/pmc_$n.log"; exit 1; }
   echo "pmc pass $n done: $counters"
   n=$((n + 1))

@@ -12,8 +12,8 @@
 typedef float v2f __attribute__((ext_vector_type(2)));
 #define ITERS 2048
 
-enum { K_FMA, K_PKFMA, K_EXP, K_RCP, K_MIX, K_CNDMASK, K_DPP, K_CNDMASK_S, K_CMP_CND, K_PKMUL, K_CMP, K_CMP_S, K_MOV, K_MAX, K_PERM32, K_MUL2, K_FMAC2, K_BLEND, K_NKINDS };
-static const char* KNAME[] = {"v_fma_f32", "v_pk_fma_f32", "v_exp_f32", "v_rcp_f32", "7 v_fma + 1 v_exp", "v_cndmask_b32 vcc", "v_add_f32 dpp", "v_cndmask_b32 sgpr", "v_cmp + v_cndmask", "v_pk_mul_f32", "v_cmp_gt_f32 vcc", "v_cmp_gt_f32 sgpr", "v_mov_b32", "v_max_f32", "v_permlane32_swap", "v_mul_f32_e32", "v_fmac_f32_e32", "forward-blend mix"};
+enum { K_FMA, K_PKFMA, K_EXP, K_RCP, K_MIX, K_CNDMASK, K_DPP, K_CNDMASK_S, K_CMP_CND, K_PKMUL, K_CMP, K_CMP_S, K_MOV, K_MAX, K_PERM32, K_MUL2, K_FMAC2, K_BLEND, K_ADD2, K_PKADD, K_NKINDS };
+static const char* KNAME[] = {"v_fma_f32", "v_pk_fma_f32", "v_exp_f32", "v_rcp_f32", "7 v_fma + 1 v_exp", "v_cndmask_b32 vcc", "v_add_f32 dpp", "v_cndmask_b32 sgpr", "v_cmp + v_cndmask", "v_pk_mul_f32", "v_cmp_gt_f32 vcc", "v_cmp_gt_f32 sgpr", "v_mov_b32", "v_max_f32", "v_permlane32_swap", "v_mul_f32_e32", "v_fmac_f32_e32", "forward-blend mix", "v_add_f32_e32", "v_pk_add_f32"};
 
 template <int KIND>
 __global__ void __launch_bounds__(1024) probe(float* out, unsigned long long* stamps, unsigned long long* sched)
@@ -23,7 +23,7 @@ __global__ void __launch_bounds__(1024) probe(float* out, unsigned long long* st
 	v2f p[8];
 #pragma unroll
 	for (int i = 0; i < 8; i++) { a[i] = 1.0f + threadIdx.x * 1e-3f + i; p[i] = v2f{a[i], a[i] + 0.5f}; }
-	const float b = 0.999f, c = 1e-3f;
+	const float b = 0.999f, c = 1e-3f, binv = 1.0f / 0.999f;
 	const v2f b2 = {b, b}, c2 = {c, c};
 	const unsigned long long smask = __builtin_amdgcn_ballot_w64(threadIdx.x & 1);
 	unsigned long long sm[4] = {0, 0, 0, 0};
@@ -49,7 +49,9 @@ __global__ void __launch_bounds__(1024) probe(float* out, unsigned long long* st
 				else if (KIND == K_MOV) asm volatile("v_mov_b32 %0, %1" : "=v"(a[i]) : "v"(b));
 				else if (KIND == K_MAX) asm volatile("v_max_f32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
 				else if (KIND == K_PERM32) asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(a[i]), "+v"(a[(i + 1) & 7]));
-				else if (KIND == K_MUL2) asm volatile("v_mul_f32_e32 %0, %1, %0" : "+v"(a[i]) : "v"(b));
+				else if (KIND == K_MUL2) { if (u & 1) asm volatile("v_mul_f32_e32 %0, %1, %0" : "+v"(a[i]) : "v"(b)); else asm volatile("v_mul_f32_e32 %0, %1, %0" : "+v"(a[i]) : "v"(binv)); }
+				else if (KIND == K_ADD2) asm volatile("v_add_f32_e32 %0, %1, %0" : "+v"(a[i]) : "v"(c));
+				else if (KIND == K_PKADD) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(p[i]) : "v"(c2));
 				else if (KIND == K_FMAC2) asm volatile("v_fmac_f32_e32 %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
 				else if (KIND == K_BLEND) {
 					// the instruction classes of one band of the forward blend (render_forward.hip), 8 instructions per accumulator
@@ -165,6 +167,8 @@ int main()
 		run<K_MUL2>(w, out, stamps, h, sched);
 		run<K_FMAC2>(w, out, stamps, h, sched);
 		run<K_BLEND>(w, out, stamps, h, sched);
+		run<K_ADD2>(w, out, stamps, h, sched);
+		run<K_PKADD>(w, out, stamps, h, sched);
 	}
 	return 0;
 }
