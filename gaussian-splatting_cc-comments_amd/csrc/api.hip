@@ -183,7 +183,7 @@ extern "C" int gsr_image_layout_of(int W, int H, gsr_image_layout* o)
 	o->n_contrib = off;        off = gsr_align_up(off + N * 4);
 	o->ranges = off;           off = gsr_align_up(off + T * 8);
 	o->tile_max_contrib = off; off = gsr_align_up(off + T * 4);
-	o->tile_order = off;       off = gsr_align_up(off + T * 4);
+	o->tile_order = off;       off = gsr_align_up(off + (T + 3 * (size_t)gsr_tile_order_max_split((int)T)) * 4);
 	o->total = off;
 	return GSR_OK;
 }
@@ -530,6 +530,8 @@ extern "C" int gsr_forward_render(int P, int64_t R, int width, int height, const
 	if (!aligned16(geometry) || !aligned16(image) || !aligned16(binning))
 		return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "state buffers must be 16-byte aligned");
 	if (R > 0xffffffffLL) return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "num_rendered exceeds 32-bit offsets");
+	if ((int64_t)gsr_grid_x(width) * gsr_grid_y(height) >= (1 << 28))  // dispatch-list entries keep the tile id in 28 bits
+		return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "image too large: more than 2^28 tiles");
 
 	GsrGeometry g = gsr_geometry_view(geometry, P);
 	GsrImage im = gsr_image_view(image, width, height);
@@ -565,7 +567,7 @@ extern "C" int gsr_forward_render(int P, int64_t R, int width, int height, const
 	if ((rc = gsr_stage_done(s, debug, "tile_ranges"))) return rc;
 	if (R > 0) {  // (measured at C3: the forward's own order is worth 33 us of blend time for ~12 us of this kernel and its launch)
 		GsrProfScope p(s, "tile_order");
-		gsr_launch_tile_order(im, ntiles, false, s);
+		gsr_launch_tile_order(im, ntiles, false, R, !(debug & GSR_DEBUG_NO_SPLIT), s);
 	}
 	if ((rc = gsr_stage_done(s, debug, "tile_order"))) return rc;
 	{
@@ -626,7 +628,7 @@ extern "C" int gsr_backward_blend(const gsr_backward_args* args)
 	GsrBinning b = gsr_binning_view(a.binning, a.P, a.num_rendered, a.width, a.height);
 	{
 		GsrProfScope p(s, "tile_order");
-		gsr_launch_tile_order(im, gsr_grid_x(a.width) * gsr_grid_y(a.height), true, s);
+		gsr_launch_tile_order(im, gsr_grid_x(a.width) * gsr_grid_y(a.height), true, a.num_rendered, false, s);
 	}
 	if ((rc = gsr_stage_done(s, a.debug, "tile_order"))) return rc;
 	{

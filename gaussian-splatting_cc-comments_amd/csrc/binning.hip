@@ -254,11 +254,20 @@ static uint32_t* g_debug_backward_key = nullptr;
 extern "C" int gsr_debug_backward_key(uint32_t* key) { g_debug_backward_key = key; return 0; }
 #endif
 
+// Forward only (split_bin_max >= 0): HEAVY tiles are handed out as four entries, one per 16x4-pixel band (entry = tile |
+// (band + 1) << 28; the forward kernel then blends that band alone, one pixel per lane).  A tile's pixels are independent, so
+// nothing changes in any result; what changes is the longest job of the launch: on a scene whose heaviest tiles carry 20-30x
+// the mean list and are walked to the end (low opacities), the one wave of the heaviest tile WAS the launch (342 of 342 us,
+// profiles/r3_tile_clock_c3_lowop.txt).  Heavy = range length >= 16 * (GSR_ORDER_BINS - 1 - split_bin_max), the heaviest
+// first, at most max_split tiles; the entries [ntiles + 3 nsplit, ntiles + 3 max_split) are marked empty.
 __global__ void __launch_bounds__(1024) gsr_tile_order_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ tile_max_contrib,
-                                                              uint32_t ntiles, uint32_t* __restrict__ order)
+                                                              uint32_t ntiles, uint32_t* __restrict__ order, int split_bin_max, uint32_t max_split,
+                                                              uint32_t* __restrict__ tile_max_contrib_out)
 {
 	__shared__ uint32_t bin[GSR_ORDER_BINS];
 	__shared__ uint32_t wsum[1024 / 64];
+	__shared__ uint32_t s_nsplit;
+	if (threadIdx.x == 0) s_nsplit = 0u;
 	bin[threadIdx.x] = 0;
 	// The kernel is one workgroup of dependent round trips: every pass reads GSR_ORDER_PER_THREAD tiles per thread with all
 	// loads issued before the first use, and the bins of the first 1024 * GSR_ORDER_PER_THREAD tiles (all of them up to
@@ -289,10 +298,25 @@ __global__ void __launch_bounds__(1024) gsr_tile_order_kernel(const uint2* __res
 	uint32_t total;
 	const uint32_t incl = gsr_block_incl_scan<1024>(c, &total, wsum);
 	bin[threadIdx.x] = incl - c;  // first position of the bin
+	// tiles of the bins 0 .. split_bin_max are split, as long as they are at most max_split: the largest such bin wins
+	if ((int)threadIdx.x <= split_bin_max && c != 0u && incl <= max_split) atomicMax(&s_nsplit, incl);
 	__syncthreads();
+	const uint32_t nsplit = s_nsplit;  // the nsplit heaviest tiles sit at positions [0, nsplit) of the order
+	// position q of the descending order -> where the entry goes; split tiles take four entries at the front
+	auto place = [&](uint32_t q, uint32_t t) {
+		if (q < nsplit) {
+#pragma unroll
+			for (uint32_t k = 0; k < 4; k++) order[4 * q + k] = t | ((k + 1u) << 28);
+			tile_max_contrib_out[t] = 0u;  // the four band waves of the tile meet there with atomicMax
+		} else {
+			order[3 * nsplit + q] = t;
+		}
+	};
+	if (split_bin_max >= 0)
+		for (uint32_t e = ntiles + 3 * nsplit + threadIdx.x; e < ntiles + 3 * max_split; e += 1024) order[e] = 0xFFFFFFFFu;
 #pragma unroll
 	for (int j = 0; j < GSR_ORDER_PER_THREAD; j++)
-		if (b0[j] != 0xffffffffu) order[atomicAdd(&bin[b0[j]], 1u)] = j * 1024 + threadIdx.x;
+		if (b0[j] != 0xffffffffu) place(atomicAdd(&bin[b0[j]], 1u), j * 1024 + threadIdx.x);
 	for (uint32_t base = 1024 * GSR_ORDER_PER_THREAD; base < ntiles; base += 1024 * GSR_ORDER_PER_THREAD) {
 		uint32_t b[GSR_ORDER_PER_THREAD];
 #pragma unroll
@@ -302,18 +326,31 @@ __global__ void __launch_bounds__(1024) gsr_tile_order_kernel(const uint2* __res
 		}
 #pragma unroll
 		for (int j = 0; j < GSR_ORDER_PER_THREAD; j++)
-			if (b[j] != 0xffffffffu) order[atomicAdd(&bin[b[j]], 1u)] = base + j * 1024 + threadIdx.x;
+			if (b[j] != 0xffffffffu) place(atomicAdd(&bin[b[j]], 1u), base + j * 1024 + threadIdx.x);
 	}
 }
 
-void gsr_launch_tile_order(GsrImage img, int ntiles, bool backward, hipStream_t s)
+// entries of the forward's dispatch list beyond the ntiles whole-tile ones: room for max_split tiles as four band entries each
+uint32_t gsr_tile_order_max_split(int ntiles) { return (uint32_t)(ntiles < 64 ? 0 : (ntiles / 8 < 512 ? ntiles / 8 : 512)); }
+
+void gsr_launch_tile_order(GsrImage img, int ntiles, bool backward, int64_t num_rendered, bool split, hipStream_t s)
 {
 	const uint32_t* key = backward ? img.tile_max_contrib : (const uint32_t*)nullptr;
 	const uint2* ranges = img.ranges;
 #ifdef GSR_TILE_CLOCK
 	if (backward && g_debug_backward_key) { key = g_debug_backward_key; ranges = nullptr; }
 #endif
-	hipLaunchKernelGGL(gsr_tile_order_kernel, dim3(1), dim3(1024), 0, s, ranges, key, (uint32_t)ntiles, img.tile_order);
+	// heavy (forward only): a list of at least 2048 instances that is also at least three times the mean list
+	int split_bin_max = -1;
+	uint32_t max_split = 0;
+	if (!backward && split && ntiles < (1 << 28)) {
+		max_split = gsr_tile_order_max_split(ntiles);
+		const int64_t mean = num_rendered / (ntiles > 0 ? ntiles : 1);
+		const int64_t heavy = mean * 3 > 2048 ? mean * 3 : 2048;
+		split_bin_max = max_split ? GSR_ORDER_BINS - 1 - (int)((heavy + 15) / 16 < GSR_ORDER_BINS - 1 ? (heavy + 15) / 16 : GSR_ORDER_BINS - 1) : -1;
+	}
+	hipLaunchKernelGGL(gsr_tile_order_kernel, dim3(1), dim3(1024), 0, s, ranges, key, (uint32_t)ntiles, img.tile_order, split_bin_max, max_split,
+	                   img.tile_max_contrib);
 }
 
 void gsr_launch_tile_ranges(const void* tile_keys, int key_bytes, int64_t R, uint2* ranges, int ntiles, uint32_t* valid, hipStream_t s)

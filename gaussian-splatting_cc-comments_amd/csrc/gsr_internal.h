@@ -110,7 +110,8 @@ void gsr_launch_mark_visible(int P, const float* means3D, const float* viewmatri
 void gsr_launch_sorted_block_sums(GsrGeometry g, int P, int result_in_alt, hipStream_t s);
 void gsr_launch_duplicate_keys(GsrGeometry g, int P, int W, void* keys, int key_bytes, uint32_t* vals, uint32_t* clear, size_t clear_words, hipStream_t s);
 void gsr_launch_tile_ranges(const void* tile_keys, int key_bytes, int64_t R, uint2* ranges, int ntiles, uint32_t* valid, hipStream_t s);
-void gsr_launch_tile_order(GsrImage img, int ntiles, bool backward, hipStream_t s);
+void gsr_launch_tile_order(GsrImage img, int ntiles, bool backward, int64_t num_rendered, bool split, hipStream_t s);
+uint32_t gsr_tile_order_max_split(int ntiles);
 
 // sort.hip
 int gsr_radix_num_passes(int nbits_total);
@@ -126,7 +127,7 @@ int gsr_tile_key_bytes(int ntiles, size_t num_rendered);
 
 // render_forward.hip
 void gsr_launch_render_forward(int W, int H, GsrImage img, const uint32_t* point_list, const GsrSplat* splat,
-                               const float* bg, float* out_color, bool ordered, bool cull, hipStream_t s);
+                               const float* bg, float* out_color, bool ordered, bool cull, hipStream_t s);   // ordered: tile_order holds ntiles + 3 * gsr_tile_order_max_split(ntiles) entries
 
 // render_backward.hip
 void gsr_launch_render_backward(int W, int H, GsrImage img, const uint32_t* point_list, const GsrSplat* splat,

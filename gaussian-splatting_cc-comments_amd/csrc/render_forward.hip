@@ -25,7 +25,7 @@
 GSR_TILE_CLOCK_BUFFER(gsr_forward_tile_clock, gsr_debug_tile_clock_forward)
 
 __global__ void __launch_bounds__(64 * GSR_WAVES_PER_WG) gsr_render_forward_wave_kernel(
-	int W, int H, int gx, int ntiles, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
+	int W, int H, int gx, int nslots, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
 	const GsrSplat* __restrict__ splat, const float* __restrict__ bg, float* __restrict__ final_T,
 	uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ tile_max_contrib, const uint32_t* __restrict__ tile_order,
 	float* __restrict__ out_color, int cull)
@@ -33,9 +33,14 @@ __global__ void __launch_bounds__(64 * GSR_WAVES_PER_WG) gsr_render_forward_wave
 	__shared__ float4 s_rec[GSR_WAVES_PER_WG][3][64];
 	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 	const int slot_id = blockIdx.x * GSR_WAVES_PER_WG + wave;
-	if (slot_id >= ntiles) return;  // wave-uniform; no barriers below
+	if (slot_id >= nslots) return;  // wave-uniform; no barriers below
 	GSR_TILE_CLOCK_START();
-	const int tile = tile_order ? (int)tile_order[slot_id] : slot_id;  // longest ranges first (binning.hip gsr_tile_order_kernel)
+	// longest ranges first (binning.hip gsr_tile_order_kernel); a heavy tile comes as four entries, one per 16x4-pixel band
+	// (bits 28..30 = band + 1): this wave then blends that band alone -- its other pixels start out "done"
+	const uint32_t entry = __builtin_amdgcn_readfirstlane(tile_order ? tile_order[slot_id] : (uint32_t)slot_id);  // a scalar: the per-band masks below stay in SGPRs
+	if (entry == 0xFFFFFFFFu) return;  // unused split entry
+	const int tile = (int)(entry & 0x0FFFFFFFu);
+	const int only = (int)(entry >> 28);  // 0: the whole tile
 	float4(*rec)[64] = s_rec[wave];
 
 	const int tx = tile % gx, ty = tile / gx;
@@ -59,7 +64,7 @@ __global__ void __launch_bounds__(64 * GSR_WAVES_PER_WG) gsr_render_forward_wave
 		pfy[k] = (float)py;
 		asm volatile("" : "+v"(pfy[k]));  // keep it in its register: the compiler would redo the conversion per instance
 		Tout[k] = 1.0f;
-		alive[k] = __builtin_amdgcn_ballot_w64(px < W && py < H);
+		alive[k] = (only == 0 || only == k + 1) ? __builtin_amdgcn_ballot_w64(px < W && py < H) : 0ull;
 		C0[k] = C1[k] = C2[k] = 0.f;
 		last[k] = 0u;
 	}
@@ -142,7 +147,7 @@ __global__ void __launch_bounds__(64 * GSR_WAVES_PER_WG) gsr_render_forward_wave
 #pragma unroll
 	for (int k = 0; k < GSR_PIX_PER_LANE; k++) {
 		const int py = py0 + 4 * k;
-		if (px < W && py < H) {
+		if (px < W && py < H && (only == 0 || only == k + 1)) {
 			const uint32_t pix_id = (uint32_t)(W * py + px);
 			final_T[pix_id] = Tout[k];
 			n_contrib[pix_id] = last[k];
@@ -154,7 +159,10 @@ __global__ void __launch_bounds__(64 * GSR_WAVES_PER_WG) gsr_render_forward_wave
 	}
 #pragma unroll
 	for (int off = 32; off > 0; off >>= 1) m = max(m, (uint32_t)__shfl_down(m, off, 64));
-	if (lane == 0) tile_max_contrib[tile] = m;
+	if (lane == 0) {
+		if (only) atomicMax(&tile_max_contrib[tile], m);  // zeroed by the order kernel for the tiles it split
+		else tile_max_contrib[tile] = m;
+	}
 	GSR_TILE_CLOCK_STOP(gsr_forward_tile_clock, tile, lane, 0ull, 0ull);
 }
 
@@ -163,8 +171,9 @@ void gsr_launch_render_forward(int W, int H, GsrImage img, const uint32_t* point
 {
 	const int gx = gsr_grid_x(W), gy = gsr_grid_y(H);
 	const int ntiles = gx * gy;
-	const int nwg = (ntiles + GSR_WAVES_PER_WG - 1) / GSR_WAVES_PER_WG;
-	hipLaunchKernelGGL(gsr_render_forward_wave_kernel, dim3(nwg), dim3(64 * GSR_WAVES_PER_WG), 0, s, W, H, gx, ntiles,
+	const int nslots = ntiles + (ordered ? 3 * (int)gsr_tile_order_max_split(ntiles) : 0);
+	const int nwg = (nslots + GSR_WAVES_PER_WG - 1) / GSR_WAVES_PER_WG;
+	hipLaunchKernelGGL(gsr_render_forward_wave_kernel, dim3(nwg), dim3(64 * GSR_WAVES_PER_WG), 0, s, W, H, gx, nslots,
 	                   img.ranges, point_list, splat, bg, img.final_T, img.n_contrib, img.tile_max_contrib,
 	                   ordered ? img.tile_order : nullptr, out_color, cull ? 1 : 0);
 }

@@ -185,6 +185,56 @@ def test_band_culling_changes_nothing(case):
         _same(a, b)
 
 
+def test_heavy_tiles_split_into_band_waves_change_nothing():
+    """A dense, low-opacity blob in the middle of the view: a few tiles carry instance lists many times the mean and are
+    walked deep.  The forward hands such tiles out as four entries, one wave per 16x4-pixel band (binning.hip
+    gsr_tile_order_kernel); GSR_DEBUG_NO_SPLIT blends them with one wave like every other tile.  Every output -- image,
+    radii, state the backward reads (final_T, n_contrib, tile_max_contrib through the gradients), all gradients -- must be
+    bit-identical, the split must actually have happened, and the image must still match the oracle."""
+    _need_gpu()
+    from diff_gaussian_rasterization import _C
+    dev = torch.device("cuda:0")
+    P, W, H, D = 60_000, 320, 200, 2
+    scene = gsr_scene.make_scene(P, -3.6, sh_degree=D, seed=9)
+    g = torch.Generator().manual_seed(10)
+    means = scene.means3D.clone()
+    means[: P * 3 // 4] = torch.randn(P * 3 // 4, 3, generator=g) * torch.tensor([0.12, 0.08, 0.3])
+    opac = scene.opacities.clone()
+    opac[: P * 3 // 4] = torch.sigmoid(torch.randn(P * 3 // 4, 1, generator=g) - 3.5)
+    scene = scene._replace(means3D=means.contiguous(), opacities=opac.contiguous())
+    cam = gsr_scene.make_camera(W, H)
+    dpix = torch.randn(3, H, W, generator=torch.Generator().manual_seed(1)).to(dev)
+    a = _direct(scene, cam, D, dpix, dev)
+    b = _direct(scene, cam, D, dpix, dev, debug=_C.DEBUG_NO_SPLIT)
+    _same(a, b)
+    # the dispatch list of the split run holds band entries (bits 28.. set)
+    st = util.hip_settings(scene, cam, D, dev)
+    e = torch.empty(0, device=dev)
+    t = {k: getattr(scene, k).to(dev) for k in ("means3D", "shs", "opacities", "scales", "rotations")}
+    R, color, radii, geom, binning, img = _C.rasterize_gaussians(st.bg, t["means3D"], e, t["opacities"], t["scales"], t["rotations"], 1.0, e,
+                                                                 st.viewmatrix, st.projmatrix, st.tanfovx, st.tanfovy, H, W, t["shs"], D,
+                                                                 st.campos, False, False)
+    T = ((W + 15) // 16) * ((H + 15) // 16)
+    il = _C.image_layout(W, H)
+    nslots = (il.total - il.tile_order) // 4
+    order = img[il.tile_order:il.tile_order + 4 * min(nslots, T + 3 * min(512, T // 8))].view(torch.int32).to(torch.int64) & 0xFFFFFFFF
+    valid = order[order != 0xFFFFFFFF]
+    band = valid >> 28
+    nsplit = int((band > 0).sum()) // 4
+    rng = img[il.ranges:il.ranges + 8 * T].view(torch.int32).view(T, 2)
+    lens = (rng[:, 1] - rng[:, 0]).to(torch.int64)
+    assert nsplit >= 1 and int((band > 0).sum()) == 4 * nsplit, "the blob's tiles must have been split"
+    assert valid.numel() == T + 3 * nsplit
+    tiles = valid & 0x0FFFFFFF
+    assert torch.equal(torch.sort(tiles[band == 0]).values, torch.sort(torch.tensor([x for x in range(T)], device=dev)[~torch.isin(torch.arange(T, device=dev), tiles[band > 0])]).values)
+    assert int(lens[tiles[band > 0]].min()) >= max(2048, 3 * (R // T)) - 16, "only heavy tiles are split"
+    o = util.oracle_forward(scene, cam, D)
+    ok = (o["fragile"] == 0).reshape(H, W)
+    assert np.array_equal(radii.cpu().numpy(), o["radii"]) and R == o["num_rendered"]
+    assert np.abs(color.cpu().numpy() - o["color"])[:, ok].max() <= 1e-5
+    print(f"split {nsplit} of {T} tiles; longest list {int(lens.max())}, mean {R // T}")
+
+
 def test_colour_kernel_beside_or_in_line_is_the_same():
     """The SH colour kernel of the forward runs on a helper stream beside the geometry kernel and the depth sort, forked
     from and joined into the caller's stream inside gsr_forward_preprocess (api.hip).  GSR_DEBUG_SERIAL runs it in line.
