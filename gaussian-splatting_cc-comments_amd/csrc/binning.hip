@@ -331,7 +331,7 @@ __global__ void __launch_bounds__(1024) gsr_tile_order_kernel(const uint2* __res
 }
 
 // entries of the forward's dispatch list beyond the ntiles whole-tile ones: room for max_split tiles as four band entries each
-uint32_t gsr_tile_order_max_split(int ntiles) { return (uint32_t)(ntiles < 64 ? 0 : (ntiles / 8 < 512 ? ntiles / 8 : 512)); }
+uint32_t gsr_tile_order_max_split(int ntiles) { return (uint32_t)(ntiles < 64 ? 0 : (ntiles / 4 < 2048 ? ntiles / 4 : 2048)); }
 
 void gsr_launch_tile_order(GsrImage img, int ntiles, bool backward, int64_t num_rendered, bool split, hipStream_t s)
 {
@@ -340,13 +340,15 @@ void gsr_launch_tile_order(GsrImage img, int ntiles, bool backward, int64_t num_
 #ifdef GSR_TILE_CLOCK
 	if (backward && g_debug_backward_key) { key = g_debug_backward_key; ranges = nullptr; }
 #endif
-	// heavy (forward only): a list of at least 2048 instances that is also at least three times the mean list
+	// heavy (forward only): a list of at least 1024 instances that is also at least twice the mean list (how deep a list is
+	// walked is not known before the forward has run; on the low-opacity blob scene the tiles that set the span were walked
+	// 2 400 - 3 300 deep whatever their length, 2 - 25 x the mean)
 	int split_bin_max = -1;
 	uint32_t max_split = 0;
 	if (!backward && split && ntiles < (1 << 28)) {
 		max_split = gsr_tile_order_max_split(ntiles);
 		const int64_t mean = num_rendered / (ntiles > 0 ? ntiles : 1);
-		const int64_t heavy = mean * 3 > 2048 ? mean * 3 : 2048;
+		const int64_t heavy = mean * 2 > 1024 ? mean * 2 : 1024;
 		split_bin_max = max_split ? GSR_ORDER_BINS - 1 - (int)((heavy + 15) / 16 < GSR_ORDER_BINS - 1 ? (heavy + 15) / 16 : GSR_ORDER_BINS - 1) : -1;
 	}
 	hipLaunchKernelGGL(gsr_tile_order_kernel, dim3(1), dim3(1024), 0, s, ranges, key, (uint32_t)ntiles, img.tile_order, split_bin_max, max_split,

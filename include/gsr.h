@@ -45,7 +45,7 @@ typedef enum {
 #define GSR_DEBUG_NO_CULL 2  /* blend kernels evaluate every (instance, pixel band) pair of a tile's list, like the reference,
                                 instead of skipping the pairs proven to contribute nothing: bisects a suspected culling error */
 #define GSR_DEBUG_SERIAL  4  /* gsr_forward_preprocess*: the SH colour kernel runs in line on `stream`, not on the helper stream */
-#define GSR_DEBUG_NO_SPLIT 8 /* gsr_forward_render: heavy tiles (instance lists >= 2048 and >= 3x the mean) are blended by one wave like
+#define GSR_DEBUG_NO_SPLIT 8 /* gsr_forward_render: heavy tiles (instance lists >= 1024 and >= 2x the mean) are blended by one wave like
                                 every other tile, not by four waves of one 16x4-pixel band each (same results either way) */
 
 /* Message of the last failing call on this thread ("" if none). */
@@ -95,7 +95,7 @@ typedef struct {
 	size_t ranges;         /* [tiles] uint2 */
 	size_t tile_max_contrib; /* [tiles] u32 = max n_contrib over the tile's pixels */
 	size_t tile_order;     /* u32 dispatch list of the blend kernels: tile ids in descending order of work; the forward's list has up to
-	                          3 * min(512, tiles / 8) further entries (heavy tiles as four band entries: tile | (band + 1) << 28) */
+	                          3 * min(2048, tiles / 4) further entries (heavy tiles as four band entries: tile | (band + 1) << 28) */
 	size_t total;
 } gsr_image_layout;
 

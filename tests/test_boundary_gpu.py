@@ -217,7 +217,7 @@ def test_heavy_tiles_split_into_band_waves_change_nothing():
     T = ((W + 15) // 16) * ((H + 15) // 16)
     il = _C.image_layout(W, H)
     nslots = (il.total - il.tile_order) // 4
-    order = img[il.tile_order:il.tile_order + 4 * min(nslots, T + 3 * min(512, T // 8))].view(torch.int32).to(torch.int64) & 0xFFFFFFFF
+    order = img[il.tile_order:il.tile_order + 4 * min(nslots, T + 3 * min(2048, T // 4))].view(torch.int32).to(torch.int64) & 0xFFFFFFFF
     valid = order[order != 0xFFFFFFFF]
     band = valid >> 28
     nsplit = int((band > 0).sum()) // 4
@@ -227,7 +227,7 @@ def test_heavy_tiles_split_into_band_waves_change_nothing():
     assert valid.numel() == T + 3 * nsplit
     tiles = valid & 0x0FFFFFFF
     assert torch.equal(torch.sort(tiles[band == 0]).values, torch.sort(torch.tensor([x for x in range(T)], device=dev)[~torch.isin(torch.arange(T, device=dev), tiles[band > 0])]).values)
-    assert int(lens[tiles[band > 0]].min()) >= max(2048, 3 * (R // T)) - 16, "only heavy tiles are split"
+    assert int(lens[tiles[band > 0]].min()) >= max(1024, 2 * (R // T)) - 16, "only heavy tiles are split"
     o = util.oracle_forward(scene, cam, D)
     ok = (o["fragile"] == 0).reshape(H, W)
     assert np.array_equal(radii.cpu().numpy(), o["radii"]) and R == o["num_rendered"]
