@@ -179,11 +179,15 @@ extern "C" int gsr_image_layout_of(int W, int H, gsr_image_layout* o)
 	if (W < 0 || H < 0 || !o) return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "gsr_image_layout_of: bad arguments");
 	const size_t N = (size_t)W * H, T = (size_t)gsr_grid_x(W) * gsr_grid_y(H);
 	size_t off = 0;
+	o->final_C = off;          off = gsr_align_up(off + 3 * N * 4);
 	o->final_T = off;          off = gsr_align_up(off + N * 4);
 	o->n_contrib = off;        off = gsr_align_up(off + N * 4);
 	o->ranges = off;           off = gsr_align_up(off + T * 8);
 	o->tile_max_contrib = off; off = gsr_align_up(off + T * 4);
-	o->tile_order = off;       off = gsr_align_up(off + (T + 3 * (size_t)gsr_tile_order_max_split((int)T)) * 4);
+	{
+		const size_t extra_f = 3 * (size_t)gsr_tile_order_max_split((int)T), extra_b = gsr_tile_order_max_segments((int)T);
+		o->tile_order = off;   off = gsr_align_up(off + (T + (extra_f > extra_b ? extra_f : extra_b) + 1) * 4);   // + the segment coarseness word
+	}
 	o->total = off;
 	return GSR_OK;
 }
@@ -199,6 +203,7 @@ extern "C" int gsr_binning_layout_of(int P, int64_t R, int W, int H, gsr_binning
 	o->tile_keys = off;      off = gsr_align_up(off + n * 4);
 	o->tile_keys_alt = off;  off = gsr_align_up(off + n * 4);
 	o->sort_table = off;     off = gsr_align_up(off + gsr_radix_table_bytes(n));
+	o->checkpoints = off;    off = gsr_align_up(off + gsr_checkpoint_records(R) * 256 * sizeof(float4));
 	o->total = off;
 	o->tile_key_bytes = (size_t)gsr_tile_key_bytes(gsr_grid_x(W) * gsr_grid_y(H), n);
 	return GSR_OK;
@@ -254,6 +259,7 @@ GsrImage gsr_image_view(void* blob, int W, int H)
 	gsr_image_layout_of(W, H, &l);
 	char* b = (char*)blob;
 	GsrImage im;
+	im.final_C = (float*)(b + l.final_C);
 	im.final_T = (float*)(b + l.final_T);
 	im.n_contrib = (uint32_t*)(b + l.n_contrib);
 	im.ranges = (uint2*)(b + l.ranges);
@@ -273,6 +279,7 @@ GsrBinning gsr_binning_view(void* blob, int P, int64_t R, int W, int H)
 	bn.tile_keys = (uint32_t*)(b + l.tile_keys);
 	bn.tile_keys_alt = (uint32_t*)(b + l.tile_keys_alt);
 	bn.sort_table = (void*)(b + l.sort_table);
+	bn.checkpoints = (float4*)(b + l.checkpoints);
 	return bn;
 }
 
@@ -572,7 +579,7 @@ extern "C" int gsr_forward_render(int P, int64_t R, int width, int height, const
 	if ((rc = gsr_stage_done(s, debug, "tile_order"))) return rc;
 	{
 		GsrProfScope p(s, "render_forward");
-				gsr_launch_render_forward(width, height, im, b.point_list, g.splat, background, out_color, R > 0, !(debug & GSR_DEBUG_NO_CULL), s);
+				gsr_launch_render_forward(width, height, im, b.point_list, g.splat, b.checkpoints, background, out_color, R > 0, !(debug & GSR_DEBUG_NO_CULL), s);
 	}
 	return gsr_stage_done(s, debug, "render_forward");
 }
@@ -628,12 +635,12 @@ extern "C" int gsr_backward_blend(const gsr_backward_args* args)
 	GsrBinning b = gsr_binning_view(a.binning, a.P, a.num_rendered, a.width, a.height);
 	{
 		GsrProfScope p(s, "tile_order");
-		gsr_launch_tile_order(im, gsr_grid_x(a.width) * gsr_grid_y(a.height), true, a.num_rendered, false, s);
+		gsr_launch_tile_order(im, gsr_grid_x(a.width) * gsr_grid_y(a.height), true, a.num_rendered, !(a.debug & GSR_DEBUG_NO_SPLIT), s);
 	}
 	if ((rc = gsr_stage_done(s, a.debug, "tile_order"))) return rc;
 	{
 		GsrProfScope p(s, "render_backward");
-		gsr_launch_render_backward(a.width, a.height, im, b.point_list, g.splat, g.slot_base, a.background, a.dL_dpix,
+		gsr_launch_render_backward(a.width, a.height, im, b.point_list, g.splat, b.checkpoints, g.slot_base, a.background, a.dL_dpix,
 		                           (GsrGradSlot*)a.scratch, (uint8_t*)b.tile_keys_alt, !(a.debug & GSR_DEBUG_NO_CULL), s);
 	}
 	return gsr_stage_done(s, a.debug, "render_backward");

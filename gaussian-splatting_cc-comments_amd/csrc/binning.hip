@@ -236,15 +236,30 @@ __global__ void __launch_bounds__(256) gsr_tile_ranges_kernel(const KeyT* __rest
 #define GSR_ORDER_PER_THREAD 9  // 9 216 tiles per pass: 1920x1080 (8 160) and 1980x1080 (8 432) in one
 // work estimate of a tile: instances the backward will stage (tile_max_contrib given) or the length of its range (the
 // forward's upper bound, before anything is known about where its pixels saturate)
-__device__ __forceinline__ uint32_t gsr_tile_work_bin(const uint2* __restrict__ ranges, const uint32_t* __restrict__ tile_max_contrib, uint32_t t)
+__device__ __forceinline__ uint32_t gsr_tile_work(const uint2* __restrict__ ranges, const uint32_t* __restrict__ tile_max_contrib, uint32_t t)
 {
 #ifdef GSR_TILE_CLOCK
-	if (!ranges) return GSR_ORDER_BINS - 1 - min(tile_max_contrib[t] >> 4, (uint32_t)GSR_ORDER_BINS - 1);  // diagnostic twin: a key supplied by the tool
+	if (!ranges) return tile_max_contrib[t];  // diagnostic twin: a key supplied by the tool
 #endif
 	const uint2 r = ranges[t];
 	uint32_t work = r.y - r.x;
 	if (tile_max_contrib) work = min(work, tile_max_contrib[t]);
+	return work;
+}
+__device__ __forceinline__ uint32_t gsr_tile_work_bin(uint32_t work)
+{
 	return GSR_ORDER_BINS - 1 - min(work >> 4, (uint32_t)GSR_ORDER_BINS - 1);  // bin 0 = most work
+}
+
+// number of depth segments the backward cuts a tile's walk of `work` instances into (1 = not cut), and their length in
+// checkpoint strides: at most GSR_CKPT_MAX_SEGMENTS segments of m strides each (render_backward.hip computes the same)
+// (`coarse` = 1, 2, 4 or 8: the order kernel doubles it until the extra entries fit its budget)
+__device__ __forceinline__ uint32_t gsr_tile_segments(uint32_t work, uint32_t coarse)
+{
+	if (work < (coarse + 1u) * GSR_CKPT_STRIDE) return 1u;
+	const uint32_t nblk = (work + GSR_CKPT_STRIDE - 1) / GSR_CKPT_STRIDE;
+	const uint32_t m = (nblk + GSR_CKPT_MAX_SEGMENTS - 1) / GSR_CKPT_MAX_SEGMENTS * coarse;
+	return (nblk + m - 1) / m;
 }
 
 #ifdef GSR_TILE_CLOCK
@@ -262,23 +277,45 @@ extern "C" int gsr_debug_backward_key(uint32_t* key) { g_debug_backward_key = ke
 // first, at most max_split tiles; the entries [ntiles + 3 nsplit, ntiles + 3 max_split) are marked empty.
 __global__ void __launch_bounds__(1024) gsr_tile_order_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ tile_max_contrib,
                                                               uint32_t ntiles, uint32_t* __restrict__ order, int split_bin_max, uint32_t max_split,
-                                                              uint32_t* __restrict__ tile_max_contrib_out)
+                                                              uint32_t* __restrict__ tile_max_contrib_out, uint32_t seg_budget)
 {
 	__shared__ uint32_t bin[GSR_ORDER_BINS];
 	__shared__ uint32_t wsum[1024 / 64];
-	__shared__ uint32_t s_nsplit;
-	if (threadIdx.x == 0) s_nsplit = 0u;
+	__shared__ uint32_t s_nsplit, s_seg_items[4], s_seg_cursor, s_incl[GSR_ORDER_BINS];
+	if (threadIdx.x == 0) { s_nsplit = 0u; s_seg_cursor = 0u; }
+	if (threadIdx.x < 4) s_seg_items[threadIdx.x] = 0u;
 	bin[threadIdx.x] = 0;
 	// The kernel is one workgroup of dependent round trips: every pass reads GSR_ORDER_PER_THREAD tiles per thread with all
 	// loads issued before the first use, and the bins of the first 1024 * GSR_ORDER_PER_THREAD tiles (all of them up to
 	// 1080p) stay in registers between the counting and the placing pass.
-	uint32_t b0[GSR_ORDER_PER_THREAD];
+	uint32_t b0[GSR_ORDER_PER_THREAD], w0[GSR_ORDER_PER_THREAD];
 #pragma unroll
 	for (int j = 0; j < GSR_ORDER_PER_THREAD; j++) {
 		const uint32_t t = j * 1024 + threadIdx.x;
-		b0[j] = t < ntiles ? gsr_tile_work_bin(ranges, tile_max_contrib, t) : 0xffffffffu;
+		w0[j] = t < ntiles ? gsr_tile_work(ranges, tile_max_contrib, t) : 0u;
+		b0[j] = t < ntiles ? gsr_tile_work_bin(w0[j]) : 0xffffffffu;
 	}
 	__syncthreads();
+	// Backward only (seg_budget > 0): a HEAVY tile -- one whose walk min(range, deepest n_contrib) is at least two checkpoint
+	// strides -- is handed out as one entry per DEPTH SEGMENT (entry = tile | (segment + 1) << 28): the forward left per-pixel
+	// (T, C) checkpoints every GSR_CKPT_STRIDE instances, so a wave can start in the middle of the list, and every segment
+	// writes the gradient slots of its own instances only.  All segment entries go to the front of the list (they belong to the
+	// heaviest tiles); if they do not fit the budget nothing is cut.
+	if (seg_budget) {   // entries the cut tiles would take, for the four coarseness levels (work values: the registers above)
+		uint32_t my_items[4] = {0u, 0u, 0u, 0u};
+		auto count = [&](uint32_t w) {
+			if (w < 2 * GSR_CKPT_STRIDE) return;   // (almost every tile)
+#pragma unroll
+			for (int f = 0; f < 4; f++)
+				if (w >= ((1u << f) + 1u) * GSR_CKPT_STRIDE) my_items[f] += gsr_tile_segments(w, 1u << f);
+		};
+#pragma unroll
+		for (int j = 0; j < GSR_ORDER_PER_THREAD; j++) count(w0[j]);
+		for (uint32_t t = 1024 * GSR_ORDER_PER_THREAD + threadIdx.x; t < ntiles; t += 1024) count(gsr_tile_work(ranges, tile_max_contrib, t));
+#pragma unroll
+		for (int f = 0; f < 4; f++)
+			if (my_items[f]) atomicAdd(&s_seg_items[f], my_items[f]);
+	}
 #pragma unroll
 	for (int j = 0; j < GSR_ORDER_PER_THREAD; j++)
 		if (b0[j] != 0xffffffffu) atomicAdd(&bin[b0[j]], 1u);
@@ -287,7 +324,7 @@ __global__ void __launch_bounds__(1024) gsr_tile_order_kernel(const uint2* __res
 #pragma unroll
 		for (int j = 0; j < GSR_ORDER_PER_THREAD; j++) {
 			const uint32_t t = base + j * 1024 + threadIdx.x;
-			b[j] = t < ntiles ? gsr_tile_work_bin(ranges, tile_max_contrib, t) : 0xffffffffu;
+			b[j] = t < ntiles ? gsr_tile_work_bin(gsr_tile_work(ranges, tile_max_contrib, t)) : 0xffffffffu;
 		}
 #pragma unroll
 		for (int j = 0; j < GSR_ORDER_PER_THREAD; j++)
@@ -300,11 +337,27 @@ __global__ void __launch_bounds__(1024) gsr_tile_order_kernel(const uint2* __res
 	bin[threadIdx.x] = incl - c;  // first position of the bin
 	// tiles of the bins 0 .. split_bin_max are split, as long as they are at most max_split: the largest such bin wins
 	if ((int)threadIdx.x <= split_bin_max && c != 0u && incl <= max_split) atomicMax(&s_nsplit, incl);
+	// depth segments: at coarseness c the tiles with work >= (c + 1) strides are cut -- exactly the bins 0 .. 1023 - 64 (c + 1) (a
+	// stride is 64 bins), a prefix of the descending order; the finest c whose extra entries (entries - tiles) fit the budget wins
+	s_incl[threadIdx.x] = incl;
 	__syncthreads();
+	uint32_t coarse = 0u, nheavy = 0u, front = 0u;
+	if (seg_budget)
+		for (int f = 0; f < 4 && !coarse; f++) {
+			const uint32_t tiles_f = s_incl[GSR_ORDER_BINS - 1 - ((1u << f) + 1u) * (GSR_CKPT_STRIDE / 16)];
+			if (s_seg_items[f] != 0u && s_seg_items[f] - tiles_f <= seg_budget) { coarse = 1u << f; nheavy = tiles_f; front = s_seg_items[f]; }
+		}
+	if (seg_budget && threadIdx.x == 0) order[ntiles + seg_budget] = coarse;   // read by the backward blend (0: nothing is cut)
 	const uint32_t nsplit = s_nsplit;  // the nsplit heaviest tiles sit at positions [0, nsplit) of the order
 	// position q of the descending order -> where the entry goes; split tiles take four entries at the front
 	auto place = [&](uint32_t q, uint32_t t) {
-		if (q < nsplit) {
+		if (q < nheavy) {   // backward: the tile's depth segments, anywhere in the front block
+			const uint32_t ns = gsr_tile_segments(gsr_tile_work(ranges, tile_max_contrib, t), coarse);
+			const uint32_t at = atomicAdd(&s_seg_cursor, ns);
+			for (uint32_t k = 0; k < ns; k++) order[at + k] = t | ((k + 1u) << 28);
+		} else if (nheavy) {
+			order[front + (q - nheavy)] = t;
+		} else if (q < nsplit) {
 #pragma unroll
 			for (uint32_t k = 0; k < 4; k++) order[4 * q + k] = t | ((k + 1u) << 28);
 			tile_max_contrib_out[t] = 0u;  // the four band waves of the tile meet there with atomicMax
@@ -314,6 +367,8 @@ __global__ void __launch_bounds__(1024) gsr_tile_order_kernel(const uint2* __res
 	};
 	if (split_bin_max >= 0)
 		for (uint32_t e = ntiles + 3 * nsplit + threadIdx.x; e < ntiles + 3 * max_split; e += 1024) order[e] = 0xFFFFFFFFu;
+	if (seg_budget)
+		for (uint32_t e = ntiles + (front - nheavy) + threadIdx.x; e < ntiles + seg_budget; e += 1024) order[e] = 0xFFFFFFFFu;
 #pragma unroll
 	for (int j = 0; j < GSR_ORDER_PER_THREAD; j++)
 		if (b0[j] != 0xffffffffu) place(atomicAdd(&bin[b0[j]], 1u), j * 1024 + threadIdx.x);
@@ -322,7 +377,7 @@ __global__ void __launch_bounds__(1024) gsr_tile_order_kernel(const uint2* __res
 #pragma unroll
 		for (int j = 0; j < GSR_ORDER_PER_THREAD; j++) {
 			const uint32_t t = base + j * 1024 + threadIdx.x;
-			b[j] = t < ntiles ? gsr_tile_work_bin(ranges, tile_max_contrib, t) : 0xffffffffu;
+			b[j] = t < ntiles ? gsr_tile_work_bin(gsr_tile_work(ranges, tile_max_contrib, t)) : 0xffffffffu;
 		}
 #pragma unroll
 		for (int j = 0; j < GSR_ORDER_PER_THREAD; j++)
@@ -331,6 +386,7 @@ __global__ void __launch_bounds__(1024) gsr_tile_order_kernel(const uint2* __res
 }
 
 // entries of the forward's dispatch list beyond the ntiles whole-tile ones: room for max_split tiles as four band entries each
+uint32_t gsr_tile_order_max_segments(int ntiles) { return (uint32_t)(ntiles < 64 ? 0 : (ntiles / 2 < 4096 ? ntiles / 2 : 4096)); }
 uint32_t gsr_tile_order_max_split(int ntiles) { return (uint32_t)(ntiles < 64 ? 0 : (ntiles / 4 < 2048 ? ntiles / 4 : 2048)); }
 
 void gsr_launch_tile_order(GsrImage img, int ntiles, bool backward, int64_t num_rendered, bool split, hipStream_t s)
@@ -351,8 +407,12 @@ void gsr_launch_tile_order(GsrImage img, int ntiles, bool backward, int64_t num_
 		const int64_t heavy = mean * 2 > 1024 ? mean * 2 : 1024;
 		split_bin_max = max_split ? GSR_ORDER_BINS - 1 - (int)((heavy + 15) / 16 < GSR_ORDER_BINS - 1 ? (heavy + 15) / 16 : GSR_ORDER_BINS - 1) : -1;
 	}
+	uint32_t seg_budget = (backward && split && ntiles < (1 << 28)) ? gsr_tile_order_max_segments(ntiles) : 0u;
+#ifdef GSR_TILE_CLOCK
+	if (!ranges) seg_budget = 0u;
+#endif
 	hipLaunchKernelGGL(gsr_tile_order_kernel, dim3(1), dim3(1024), 0, s, ranges, key, (uint32_t)ntiles, img.tile_order, split_bin_max, max_split,
-	                   img.tile_max_contrib);
+	                   img.tile_max_contrib, seg_budget);
 }
 
 void gsr_launch_tile_ranges(const void* tile_keys, int key_bytes, int64_t R, uint2* ranges, int ntiles, uint32_t* valid, hipStream_t s)

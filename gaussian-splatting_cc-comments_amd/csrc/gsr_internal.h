@@ -41,7 +41,17 @@ struct GsrGeometry {
 	void* sort_table;             // radix histogram table for the P-sized depth sort
 };
 
+// Depth checkpoints of heavy tiles (lists of at least 2 * GSR_CKPT_STRIDE instances): every GSR_CKPT_STRIDE instances the forward
+// blend stores each pixel's running (T, C) BEFORE the instance at that position; the backward blend can then start in the middle
+// of a list (render_backward.hip).  One 4-KB record (256 pixels x float4) per checkpoint, indexed by the checkpoint's position in the
+// global sorted instance list: record (range.x + p) / GSR_CKPT_STRIDE for local position p -- tiles own disjoint ranges and only
+// tiles of at least two strides store any, so no two checkpoints share a record.
+#define GSR_CKPT_STRIDE 1024
+#define GSR_CKPT_MAX_SEGMENTS 15   // segments a heavy tile's walk is cut into at most (4 bits of the dispatch entry, 0 = whole tile)
+static inline size_t gsr_checkpoint_records(int64_t R) { return (size_t)(R / GSR_CKPT_STRIDE) + 2; }
+
 struct GsrImage {
+	float* final_C;            // [3][W*H] accumulated colour without the background term (heavy tiles only: the backward's segments need it)
 	float* final_T;
 	uint32_t* n_contrib;
 	uint2* ranges;
@@ -55,6 +65,7 @@ struct GsrBinning {
 	uint32_t* tile_keys;       // sorted tile ids (final)
 	uint32_t* tile_keys_alt;   // after the forward: [R] validity BYTES of the backward's gradient slots (zeroed by tile_ranges)
 	void* sort_table;          // radix histogram table for the R-sized tile sort
+	float4* checkpoints;       // [gsr_checkpoint_records(R)][256] depth checkpoints of heavy tiles (see GSR_CKPT_STRIDE)
 };
 
 GsrGeometry gsr_geometry_view(void* blob, int P);
@@ -111,7 +122,8 @@ void gsr_launch_sorted_block_sums(GsrGeometry g, int P, int result_in_alt, hipSt
 void gsr_launch_duplicate_keys(GsrGeometry g, int P, int W, void* keys, int key_bytes, uint32_t* vals, uint32_t* clear, size_t clear_words, hipStream_t s);
 void gsr_launch_tile_ranges(const void* tile_keys, int key_bytes, int64_t R, uint2* ranges, int ntiles, uint32_t* valid, hipStream_t s);
 void gsr_launch_tile_order(GsrImage img, int ntiles, bool backward, int64_t num_rendered, bool split, hipStream_t s);
-uint32_t gsr_tile_order_max_split(int ntiles);
+uint32_t gsr_tile_order_max_split(int ntiles);      // forward: tiles that may be split into four band entries
+uint32_t gsr_tile_order_max_segments(int ntiles);   // backward: extra entries for the depth segments of heavy tiles
 
 // sort.hip
 int gsr_radix_num_passes(int nbits_total);
@@ -126,11 +138,11 @@ void gsr_radix_sort_u32(void* k0, uint32_t* v0, void* k1, uint32_t* v1, size_t n
 int gsr_tile_key_bytes(int ntiles, size_t num_rendered);
 
 // render_forward.hip
-void gsr_launch_render_forward(int W, int H, GsrImage img, const uint32_t* point_list, const GsrSplat* splat,
+void gsr_launch_render_forward(int W, int H, GsrImage img, const uint32_t* point_list, const GsrSplat* splat, float4* checkpoints,
                                const float* bg, float* out_color, bool ordered, bool cull, hipStream_t s);   // ordered: tile_order holds ntiles + 3 * gsr_tile_order_max_split(ntiles) entries
 
 // render_backward.hip
-void gsr_launch_render_backward(int W, int H, GsrImage img, const uint32_t* point_list, const GsrSplat* splat,
+void gsr_launch_render_backward(int W, int H, GsrImage img, const uint32_t* point_list, const GsrSplat* splat, const float4* checkpoints,
                                 const uint32_t* slot_base, const float* bg, const float* dL_dpix, GsrGradSlot* slots,
                                 uint8_t* slot_valid, bool cull, hipStream_t s);
 

@@ -29,8 +29,8 @@ __device__ __forceinline__ float gsr_add_halves(v2f a)
 }
 
 __global__ void __launch_bounds__(64 * GSR_WAVES_PER_WG) __attribute__((amdgpu_waves_per_eu(4, 4))) gsr_render_backward_wave_kernel(
-	int W, int H, int gx, int ntiles, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
-	const GsrSplat* __restrict__ splat, const uint32_t* __restrict__ slot_base, const float* __restrict__ bg,
+	int W, int H, int gx, int nslots, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
+	const GsrSplat* __restrict__ splat, const float4* __restrict__ checkpoints, const float* __restrict__ final_C, const uint32_t* __restrict__ slot_base, const float* __restrict__ bg,
 	const float* __restrict__ final_Ts, const uint32_t* __restrict__ n_contrib, const uint32_t* __restrict__ tile_max_contrib,
 	const uint32_t* __restrict__ tile_order, const float* __restrict__ dL_dpixels, GsrGradSlot* __restrict__ slots,
 	uint8_t* __restrict__ slot_valid, int cull)
@@ -46,12 +46,17 @@ __global__ void __launch_bounds__(64 * GSR_WAVES_PER_WG) __attribute__((amdgpu_w
 	__shared__ float s_red[GSR_WAVES_PER_WG][64 * 9 + 8];
 	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 	const int slot_id = blockIdx.x * GSR_WAVES_PER_WG + wave;
-	if (slot_id >= ntiles) return;  // wave-uniform; no barriers below
+	if (slot_id >= nslots) return;  // wave-uniform; no barriers below
 	GSR_TILE_CLOCK_START();
 	GSR_TILE_STAT(unsigned long long st_staged = 0; unsigned long long st_pairs = 0; unsigned long long st_pairs_hit = 0; unsigned long long st_reductions = 0; unsigned long long st_lanes_hit = 0;)
 	// workgroups are dispatched in index order: tile_order lists the tiles by descending work, so the long tiles
 	// start first and the short ones fill the end of the launch (binning.hip gsr_tile_order_kernel)
-	const int tile = (int)tile_order[slot_id];
+	// A heavy tile (walk of at least two checkpoint strides) comes as one entry per DEPTH SEGMENT (bits 28..31 = segment + 1):
+	// this wave then walks the positions [a, b) of the list only, starting from the per-pixel (T, C) the forward left at b.
+	const uint32_t entry = __builtin_amdgcn_readfirstlane(tile_order[slot_id]);
+	if (entry == 0xFFFFFFFFu) return;  // unused segment entry
+	const int tile = (int)(entry & 0x0FFFFFFFu);
+	const int seg1 = (int)(entry >> 28);  // 0: the whole tile
 	float4(*rec)[64] = s_rec[wave];
 	uint32_t* recb = s_bands[wave];
 
@@ -63,6 +68,14 @@ __global__ void __launch_bounds__(64 * GSR_WAVES_PER_WG) __attribute__((amdgpu_w
 
 	const uint2 range = ranges[tile];
 	const int n = (int)min(range.y - range.x, tile_max_contrib[tile]);  // the tail was never blended
+	int seg_a = 0, top = n;   // positions [seg_a, top) of the walk are this wave's
+	if (seg1) {               // (binning.hip gsr_tile_segments: the same cut; its coarseness sits behind the list's last entry)
+		const int coarse = (int)__builtin_amdgcn_readfirstlane(tile_order[nslots]);
+		const int nblk = (n + GSR_CKPT_STRIDE - 1) / GSR_CKPT_STRIDE, m = (nblk + GSR_CKPT_MAX_SEGMENTS - 1) / GSR_CKPT_MAX_SEGMENTS * coarse;
+		seg_a = (seg1 - 1) * m * GSR_CKPT_STRIDE;
+		top = min(n, seg1 * m * GSR_CKPT_STRIDE);
+	}
+	const int nw = top - seg_a;
 	const uint32_t* plist = point_list + range.x;
 	const size_t plane = (size_t)H * W;
 	const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
@@ -94,6 +107,29 @@ __global__ void __launch_bounds__(64 * GSR_WAVES_PER_WG) __attribute__((amdgpu_w
 	}
 #pragma unroll
 	for (int p = 0; p < 2; p++) ac0[p] = ac1[p] = ac2[p] = v2f{0.f, 0.f};
+	if (top < n) {
+		// The walk starts in the middle of the list.  The forward stored every pixel's (T, C) before the instance at position
+		// `top`; what lies behind it blended to C_final - C, seen through T: the running T is the checkpoint's, and accum_rec --
+		// the colour accumulated behind the current instance, backward.cu:553 -- is (C_final - C) / T.  A pixel whose last
+		// contributor lies in front of `top` (n_contrib <= top) has nothing behind the segment: it starts from its final state,
+		// T_final and 0, like a whole-tile walk -- and its checkpoint is not read (a band wave of the forward that finished early
+		// wrote none).
+		const float4* ck = checkpoints + ((size_t)(range.x + (uint32_t)top) / GSR_CKPT_STRIDE) * 256 + lane;
+#pragma unroll
+		for (int k = 0; k < GSR_PIX_PER_LANE; k++) {
+			const int py = py0 + 4 * k;
+			const bool inside = px < W && py < H;
+			const uint32_t pix_id = inside ? (uint32_t)(W * py + px) : 0u;
+			if (inside && last_contributor[k] > top) {
+				const float4 c = ck[64 * k];
+				const float inv = 1.0f / c.x;   // T before an instance that still contributed: > 1e-4
+				T[k >> 1][k & 1] = c.x;
+				ac0[k >> 1][k & 1] = (final_C[pix_id] - c.y) * inv;
+				ac1[k >> 1][k & 1] = (final_C[plane + pix_id] - c.z) * inv;
+				ac2[k >> 1][k & 1] = (final_C[2 * plane + pix_id] - c.w) * inv;
+			}
+		}
+	}
 	// wave-uniform: the largest n_contrib among the 128 pixels of each pair; instances at or beyond it
 	// were blended into none of them, so the pair is skipped without evaluating anything
 	int pair_last[2];
@@ -105,24 +141,24 @@ __global__ void __launch_bounds__(64 * GSR_WAVES_PER_WG) __attribute__((amdgpu_w
 		pair_last[p] = __builtin_amdgcn_readfirstlane(m);
 	}
 
-	// back to front: batch position q = base + lane maps to range position n - 1 - q
+	// back to front: batch position q = base + lane maps to range position top - 1 - q (top = n for a whole tile, the end of the segment otherwise)
 	float4 ra = make_float4(0, 0, 0, 0), rb = ra, rc = ra;
 	uint32_t sbase = 0u;  // first gradient slot of the staged Gaussian (dense per-Gaussian array, cache resident)
-	if (lane < n) {
-		const uint32_t id = plist[n - 1 - lane];
+	if (lane < nw) {
+		const uint32_t id = plist[top - 1 - lane];
 		const float4* p = reinterpret_cast<const float4*>(splat + id);
 		ra = p[0]; rb = p[1]; rc = p[2];
 		sbase = slot_base[id];
 	}
-	uint32_t id_next = (64 + lane < n) ? plist[n - 1 - (64 + lane)] : 0u;
+	uint32_t id_next = (64 + lane < nw) ? plist[top - 1 - (64 + lane)] : 0u;
 	const int out_index = lane >> 3;                  // 8-lane group c ends up holding the wave total of v[c]
 	float* const red_w = s_red[wave] + lane * 9;                       // this lane's row
 	const float* const red_r = s_red[wave] + (lane & 7) * 9 + (lane >> 3);   // column lane / 8, rows (lane % 8) + 8 k
 	const float out_scale = (out_index >= 2 && out_index <= 4) ? -0.5f : 1.0f;
 	const float k01 = out_index == 0 ? -ddelx_dx : -ddely_dy;   // backward.cu:574-575: dL/dmean2D is scaled by 0.5 W / 0.5 H
 
-	for (int base = 0; base < n; base += 64) {
-		const uint32_t bands = (base + lane < n) ? (cull ? gsr_tile_band_mask(ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, x0f, y0f) : 0xFu) : 0u;
+	for (int base = 0; base < nw; base += 64) {
+		const uint32_t bands = (base + lane < nw) ? (cull ? gsr_tile_band_mask(ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, x0f, y0f) : 0xFu) : 0u;
 		const bool keep = bands != 0u;
 		const unsigned long long mask = __builtin_amdgcn_ballot_w64(keep);
 		const int cnt = __popcll(mask);
@@ -137,15 +173,15 @@ __global__ void __launch_bounds__(64 * GSR_WAVES_PER_WG) __attribute__((amdgpu_w
 			rec[1][pos] = make_float4(-0.5f * ra.z, -0.5f * ra.z, ra.w, ra.w);  // -0.5 conic a, conic b
 			rec[2][pos] = make_float4(-0.5f * rb.x, -0.5f * rb.x, rb.y, rb.y);  // -0.5 conic c, opacity
 			rec[3][pos] = make_float4(rc.x, rc.x, rc.y, rc.y);  // r, g
-			rec[4][pos] = make_float4(rc.z, rc.z, __int_as_float(n - 1 - (base + lane)), __uint_as_float(slot));  // b, position in the full range, slot
+			rec[4][pos] = make_float4(rc.z, rc.z, __int_as_float(top - 1 - (base + lane)), __uint_as_float(slot));  // b, position in the full range, slot
 			recb[pos] = bands;
 		}
-		if (base + 64 + lane < n) {
+		if (base + 64 + lane < nw) {
 			const float4* p = reinterpret_cast<const float4*>(splat + id_next);
 			ra = p[0]; rb = p[1]; rc = p[2];
 			sbase = slot_base[id_next];
 		}
-		id_next = (base + 128 + lane < n) ? plist[n - 1 - (base + 128 + lane)] : 0u;
+		id_next = (base + 128 + lane < nw) ? plist[top - 1 - (base + 128 + lane)] : 0u;
 		__builtin_amdgcn_wave_barrier();
 
 		for (int j = 0; j < cnt; j++) {
@@ -269,14 +305,15 @@ __global__ void __launch_bounds__(64 * GSR_WAVES_PER_WG) __attribute__((amdgpu_w
 	GSR_TILE_CLOCK_STOP(gsr_backward_tile_clock, tile, lane, st_staged | (st_pairs << 20) | (st_pairs_hit << 42), st_reductions | (st_lanes_hit << 24));
 }
 
-void gsr_launch_render_backward(int W, int H, GsrImage img, const uint32_t* point_list, const GsrSplat* splat,
+void gsr_launch_render_backward(int W, int H, GsrImage img, const uint32_t* point_list, const GsrSplat* splat, const float4* checkpoints,
                                 const uint32_t* slot_base, const float* bg, const float* dL_dpix, GsrGradSlot* slots,
                                 uint8_t* slot_valid, bool cull, hipStream_t s)
 {
 	const int gx = gsr_grid_x(W), gy = gsr_grid_y(H);
 	const int ntiles = gx * gy;
-	const int nwg = (ntiles + GSR_WAVES_PER_WG - 1) / GSR_WAVES_PER_WG;
-	hipLaunchKernelGGL(gsr_render_backward_wave_kernel, dim3(nwg), dim3(64 * GSR_WAVES_PER_WG), 0, s, W, H, gx, ntiles,
-	                   img.ranges, point_list, splat, slot_base, bg, img.final_T, img.n_contrib, img.tile_max_contrib,
+	const int nslots = ntiles + (int)gsr_tile_order_max_segments(ntiles);   // whole tiles + the extra entries of heavy tiles' depth segments
+	const int nwg = (nslots + GSR_WAVES_PER_WG - 1) / GSR_WAVES_PER_WG;
+	hipLaunchKernelGGL(gsr_render_backward_wave_kernel, dim3(nwg), dim3(64 * GSR_WAVES_PER_WG), 0, s, W, H, gx, nslots,
+	                   img.ranges, point_list, splat, checkpoints, img.final_C, slot_base, bg, img.final_T, img.n_contrib, img.tile_max_contrib,
 	                   img.tile_order, dL_dpix, slots, slot_valid, cull ? 1 : 0);
 }

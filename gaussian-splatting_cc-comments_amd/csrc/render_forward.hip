@@ -24,9 +24,9 @@
 
 GSR_TILE_CLOCK_BUFFER(gsr_forward_tile_clock, gsr_debug_tile_clock_forward)
 
-__global__ void __launch_bounds__(64 * GSR_WAVES_PER_WG) gsr_render_forward_wave_kernel(
+__global__ void __launch_bounds__(64 * GSR_WAVES_PER_WG) __attribute__((amdgpu_waves_per_eu(6, 6))) gsr_render_forward_wave_kernel(
 	int W, int H, int gx, int nslots, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
-	const GsrSplat* __restrict__ splat, const float* __restrict__ bg, float* __restrict__ final_T,
+	const GsrSplat* __restrict__ splat, float4* __restrict__ checkpoints, float* __restrict__ final_C, const float* __restrict__ bg, float* __restrict__ final_T,
 	uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ tile_max_contrib, const uint32_t* __restrict__ tile_order,
 	float* __restrict__ out_color, int cull)
 {
@@ -53,6 +53,8 @@ __global__ void __launch_bounds__(64 * GSR_WAVES_PER_WG) gsr_render_forward_wave
 	const uint2 range = ranges[tile];
 	const int n = (int)(range.y - range.x);
 	const uint32_t* plist = point_list + range.x;
+	// a heavy tile leaves depth checkpoints for the backward (gsr_internal.h GSR_CKPT_STRIDE): wave-uniform
+	const bool heavy = n >= 2 * GSR_CKPT_STRIDE;
 
 	float Tout[GSR_PIX_PER_LANE], C0[GSR_PIX_PER_LANE], C1[GSR_PIX_PER_LANE], C2[GSR_PIX_PER_LANE];
 	float pfy[GSR_PIX_PER_LANE];
@@ -80,6 +82,13 @@ __global__ void __launch_bounds__(64 * GSR_WAVES_PER_WG) gsr_render_forward_wave
 
 	for (int base = 0; base < n; base += 64) {
 		if ((alive[0] | alive[1] | alive[2] | alive[3]) == 0ull) break;
+		if (heavy && base != 0 && (base & (GSR_CKPT_STRIDE - 1)) == 0) {
+			// every pixel's state BEFORE the instance at position `base` (a finished pixel's state is its final one)
+			float4* ck = checkpoints + ((size_t)(range.x + (uint32_t)base) / GSR_CKPT_STRIDE) * 256 + lane;
+#pragma unroll
+			for (int k = 0; k < GSR_PIX_PER_LANE; k++)
+				if (only == 0 || only == k + 1) ck[64 * k] = make_float4(Tout[k], C0[k], C1[k], C2[k]);
+		}
 		const uint32_t bands = (base + lane < n) ? (cull ? gsr_tile_band_mask(ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, x0f, y0f) : 0xFu) : 0u;
 		const bool keep = bands != 0u;
 		const unsigned long long mask = __builtin_amdgcn_ballot_w64(keep);
@@ -154,6 +163,7 @@ __global__ void __launch_bounds__(64 * GSR_WAVES_PER_WG) gsr_render_forward_wave
 			out_color[pix_id] = C0[k] + Tout[k] * bg0;
 			out_color[plane + pix_id] = C1[k] + Tout[k] * bg1;
 			out_color[2 * plane + pix_id] = C2[k] + Tout[k] * bg2;
+			if (heavy) { final_C[pix_id] = C0[k]; final_C[plane + pix_id] = C1[k]; final_C[2 * plane + pix_id] = C2[k]; }
 			m = max(m, last[k]);
 		}
 	}
@@ -166,7 +176,7 @@ __global__ void __launch_bounds__(64 * GSR_WAVES_PER_WG) gsr_render_forward_wave
 	GSR_TILE_CLOCK_STOP(gsr_forward_tile_clock, tile, lane, 0ull, 0ull);
 }
 
-void gsr_launch_render_forward(int W, int H, GsrImage img, const uint32_t* point_list, const GsrSplat* splat,
+void gsr_launch_render_forward(int W, int H, GsrImage img, const uint32_t* point_list, const GsrSplat* splat, float4* checkpoints,
                                const float* bg, float* out_color, bool ordered, bool cull, hipStream_t s)
 {
 	const int gx = gsr_grid_x(W), gy = gsr_grid_y(H);
@@ -174,6 +184,6 @@ void gsr_launch_render_forward(int W, int H, GsrImage img, const uint32_t* point
 	const int nslots = ntiles + (ordered ? 3 * (int)gsr_tile_order_max_split(ntiles) : 0);
 	const int nwg = (nslots + GSR_WAVES_PER_WG - 1) / GSR_WAVES_PER_WG;
 	hipLaunchKernelGGL(gsr_render_forward_wave_kernel, dim3(nwg), dim3(64 * GSR_WAVES_PER_WG), 0, s, W, H, gx, nslots,
-	                   img.ranges, point_list, splat, bg, img.final_T, img.n_contrib, img.tile_max_contrib,
+	                   img.ranges, point_list, splat, checkpoints, img.final_C, bg, img.final_T, img.n_contrib, img.tile_max_contrib,
 	                   ordered ? img.tile_order : nullptr, out_color, cull ? 1 : 0);
 }

@@ -32,12 +32,12 @@ class GeometryLayout(ctypes.Structure):
 
 
 class ImageLayout(ctypes.Structure):
-    _fields_ = [(n, _sz) for n in ("final_T", "n_contrib", "ranges", "tile_max_contrib", "tile_order", "total")]
+    _fields_ = [(n, _sz) for n in ("final_C", "final_T", "n_contrib", "ranges", "tile_max_contrib", "tile_order", "total")]
 
 
 class BinningLayout(ctypes.Structure):
     _fields_ = [(n, _sz) for n in ("point_list", "point_list_alt", "tile_keys", "tile_keys_alt", "sort_table",
-                                   "total", "tile_key_bytes")]
+                                   "checkpoints", "total", "tile_key_bytes")]
 
 
 class KernelTime(ctypes.Structure):

@@ -90,6 +90,7 @@ typedef struct {
 } gsr_geometry_layout;
 
 typedef struct {
+	size_t final_C;        /* [3][W*H] f32 accumulated colour without the background term; written for heavy tiles only */
 	size_t final_T;        /* [W*H] f32 */
 	size_t n_contrib;      /* [W*H] u32 */
 	size_t ranges;         /* [tiles] uint2 */
@@ -105,6 +106,7 @@ typedef struct {
 	size_t tile_keys;      /* [R] tile id of each sorted instance (the high word of the reference's key), tile_key_bytes each */
 	size_t tile_keys_alt;  /* [R] sort ping-pong; after the forward its first R bytes are the backward's slot validity flags */
 	size_t sort_table;     /* radix histogram table of the tile sort */
+	size_t checkpoints;    /* [R / 1024 + 2][256] float4: per-pixel (T, C) of heavy tiles every 1024 instances of their walk */
 	size_t total;
 	size_t tile_key_bytes; /* 2 (uint16_t: every tile id of the image is below 65 536) or 4 (uint32_t); both arrays are sized for 4 */
 } gsr_binning_layout;
