@@ -13,6 +13,13 @@
 #include "gsr_internal.h"
 
 #define GSR_MAX_DEVICES 64
+// Beside the depth sort the SH colour kernel is held to two workgroups per CU (40 KB of unused dynamic LDS each): it has until the
+// end of the depth sort to finish, and at full occupancy its memory traffic doubled the latency-bound first launches of that sort
+// (histogram 6 -> 15 us, scatter 13 -> 25).  Measured at C3: step 1.167 -> 1.160 ms with two workgroups per CU (three: 1.161, one:
+// 1.161).  Only while the colour kernel is the shorter of the two: its time grows with P, the depth sort's barely (C5, 6M
+// Gaussians: colour 0.42 ms against 0.25 ms of sort -- there it keeps the whole chip).
+#define GSR_COLOR_BESIDE_LDS (40 * 1024)
+#define GSR_COLOR_BESIDE_MAX_P 1500000
 
 // ---- errors ------------------------------------------------------------------------------------
 static thread_local char g_err[512] = "";
@@ -429,7 +436,7 @@ static int gsr_forward_preprocess_impl(int P, int D, int M, int width, int heigh
 		// fork: the helper stream starts where the caller's stream stands now (its inputs are ready there)
 		if ((rc = gsr_check_hip(hipEventRecord(td.aux_fork, s), "hipEventRecord(fork)"))) return rc;
 		if ((rc = gsr_check_hip(hipStreamWaitEvent(td.aux_stream, td.aux_fork, 0), "hipStreamWaitEvent(fork)"))) return rc;
-		gsr_launch_preprocess_color(a, td.aux_stream);
+		gsr_launch_preprocess_color(a, td.aux_stream, P <= GSR_COLOR_BESIDE_MAX_P ? GSR_COLOR_BESIDE_LDS : 0);
 		if (hipEventRecord(td.aux_join, td.aux_stream) != hipSuccess) {
 			(void)hipStreamSynchronize(td.aux_stream);  // no event to wait for: wait on the host instead, then report
 			return gsr_fail(GSR_ERR_HIP, "hipEventRecord(join) failed");

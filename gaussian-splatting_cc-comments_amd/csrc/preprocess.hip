@@ -254,16 +254,18 @@ void gsr_launch_preprocess(const GsrPreprocessArgs& a, hipStream_t s)
 // the colour kernel exists only for SH colours
 bool gsr_preprocess_needs_color(const GsrPreprocessArgs& a) { return a.shs && !a.colors_precomp; }
 
-void gsr_launch_preprocess_color(const GsrPreprocessArgs& a, hipStream_t s)
+// throttle: bytes of (unused) dynamic LDS per workgroup -- limits how many workgroups of this kernel a CU holds at once when it
+// runs beside the depth sort on the helper stream (api.hip)
+void gsr_launch_preprocess_color(const GsrPreprocessArgs& a, hipStream_t s, size_t throttle)
 {
 	const int nb = (a.P + GSR_PREPROCESS_BLOCK - 1) / GSR_PREPROCESS_BLOCK;
 	// LDS-transposed SH path: the flagship layout (16 coefficients), 16-byte aligned tensor
 	int sh_via_lds = (a.M == 16 && ((uintptr_t)a.shs & 15u) == 0) ? 1 : 0;
 	if (a.leaf) {
 		if (((uintptr_t)a.shs_rest & 15u) != 0) sh_via_lds = 0;
-		hipLaunchKernelGGL(gsr_preprocess_color_kernel<true>, dim3(nb), dim3(GSR_PREPROCESS_BLOCK), 0, s, a, sh_via_lds);
+		hipLaunchKernelGGL(gsr_preprocess_color_kernel<true>, dim3(nb), dim3(GSR_PREPROCESS_BLOCK), throttle, s, a, sh_via_lds);
 	} else {
-		hipLaunchKernelGGL(gsr_preprocess_color_kernel<false>, dim3(nb), dim3(GSR_PREPROCESS_BLOCK), 0, s, a, sh_via_lds);
+		hipLaunchKernelGGL(gsr_preprocess_color_kernel<false>, dim3(nb), dim3(GSR_PREPROCESS_BLOCK), throttle, s, a, sh_via_lds);
 	}
 }
 
