@@ -302,7 +302,7 @@ __global__ void __launch_bounds__(64 * GSR_WAVES_PER_WG) __attribute__((amdgpu_w
 		}
 		__builtin_amdgcn_wave_barrier();
 	}
-	GSR_TILE_CLOCK_STOP(gsr_backward_tile_clock, tile, lane, st_staged | (st_pairs << 20) | (st_pairs_hit << 42), st_reductions | (st_lanes_hit << 24));
+	GSR_TILE_CLOCK_STOP(gsr_backward_tile_clock, slot_id, lane, st_staged | (st_pairs << 20) | (st_pairs_hit << 42), st_reductions | (st_lanes_hit << 24));   // one record per dispatch entry
 }
 
 void gsr_launch_render_backward(int W, int H, GsrImage img, const uint32_t* point_list, const GsrSplat* splat, const float4* checkpoints,

@@ -173,7 +173,7 @@ __global__ void __launch_bounds__(64 * GSR_WAVES_PER_WG) __attribute__((amdgpu_w
 		if (only) atomicMax(&tile_max_contrib[tile], m);  // zeroed by the order kernel for the tiles it split
 		else tile_max_contrib[tile] = m;
 	}
-	GSR_TILE_CLOCK_STOP(gsr_forward_tile_clock, tile, lane, 0ull, 0ull);
+	GSR_TILE_CLOCK_STOP(gsr_forward_tile_clock, slot_id, lane, (unsigned long long)entry, 0ull);   // one record per dispatch entry
 }
 
 void gsr_launch_render_forward(int W, int H, GsrImage img, const uint32_t* point_list, const GsrSplat* splat, float4* checkpoints,

@@ -122,7 +122,10 @@ def main():
     rasterizer = GaussianRasterizer(settings)
     dpix = to(torch.randn(3, H, W, generator=torch.Generator().manual_seed(1)))
     ntiles = ((W + 15) // 16) * ((H + 15) // 16)
-    bufs = {k: torch.zeros(ntiles, 8, dtype=torch.int64, device=dev) for k in ("forward", "backward")}
+    # one record per DISPATCH ENTRY (a heavy tile is several: four band waves in the forward, one wave per depth segment in the
+    # backward): room for the whole lists; unused entries keep t1 = 0 and are dropped by analyse()
+    nrec = ntiles + 3 * min(2048, ntiles // 4) + min(4096, ntiles // 2) + 1
+    bufs = {k: torch.zeros(nrec, 8, dtype=torch.int64, device=dev) for k in ("forward", "backward")}
 
     captured = {}
     orig = _C.rasterize_gaussians
@@ -153,7 +156,7 @@ def main():
         getattr(L, f"gsr_debug_tile_clock_{k}")(None)
     out = open(a.out, "w") if a.out else sys.stdout
     print(f"# tools/tile_clock.py --config {a.config} --scene {a.scene}: P={P} {W}x{H}, {ntiles} tiles, one wave64 per tile; clocks on the 100 MHz constant clock", file=out)
-    analyse("render_forward (<= 5 waves per SIMD by its 88 VGPRs)", bufs["forward"].cpu().numpy(), 5, out)
+    analyse("render_forward (6 waves per SIMD, 80 VGPRs)", bufs["forward"].cpu().numpy(), 6, out)
     analyse("render_backward (4 waves per SIMD, 128 VGPRs)", bufs["backward"].cpu().numpy(), 4, out)
     # how well does the dispatch key predict a tile's duration?
     il = _C.image_layout(W, H)
@@ -162,7 +165,17 @@ def main():
     tmc = img[il.tile_max_contrib:il.tile_max_contrib + 4 * ntiles].view(np.uint32).astype(np.int64)
     length = ranges[:, 1] - ranges[:, 0]
     staged = np.minimum(length, tmc)
-    f, b = bufs["forward"].cpu().numpy(), bufs["backward"].cpu().numpy()
+    if a.scene != "uniform":   # (per-tile keys against per-ENTRY durations only line up when nothing is split)
+        if a.out:
+            out.close()
+            print(open(a.out).read())
+        return
+    f, b = bufs["forward"].cpu().numpy()[:ntiles], bufs["backward"].cpu().numpy()[:ntiles]
+    # records are in dispatch order: bring them into tile order through the dispatch lists (whole-tile entries only)
+    order_f = f[:, 6] & 0x0FFFFFFF
+    tmp = np.zeros_like(f); tmp[order_f] = f; f = tmp
+    tile_order_b = img[il.tile_order:il.tile_order + 4 * ntiles].view(np.uint32).astype(np.int64) & 0x0FFFFFFF
+    tmp = np.zeros_like(b); tmp[tile_order_b] = b; b = tmp
     fd, bd = (f[:, 1] - f[:, 0]) * 0.01, (b[:, 1] - b[:, 0]) * 0.01
     rank = lambda x: np.argsort(np.argsort(x))
     rc = lambda x, y: float(np.corrcoef(rank(x), rank(y))[0, 1])
@@ -189,7 +202,10 @@ def main():
             step()
             torch.cuda.synchronize()
             fnb(None)
-            cur = bufs["backward"].cpu().numpy()
+            rec = bufs["backward"].cpu().numpy()[:ntiles]
+            lst = captured["img"].cpu().numpy()[il.tile_order:il.tile_order + 4 * ntiles].view(np.uint32).astype(np.int64) & 0x0FFFFFFF
+            cur = np.zeros_like(rec)
+            cur[lst] = rec   # dispatch order -> tile order
             print(f"   round {rnd + 1}, by the durations of the previous round: span {span(cur):.1f} us", file=out)
         L.gsr_debug_backward_key(None)
     if a.dump:
