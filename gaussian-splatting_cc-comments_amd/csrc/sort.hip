@@ -41,7 +41,9 @@
 #ifndef GSR_WALK_ROWS
 #define GSR_WALK_ROWS 8    // rows of the offset tables a wave keeps in flight (one uint4 per lane each)
 #endif
+#ifndef GSR_SORT_CHUNK
 #define GSR_SORT_CHUNK 64   // blocks per chunk, chunks per super-chunk of the three-level offset table
+#endif
 
 // min / range of the biased keys from the 64 + 64 partial maxima {max(~key)}, {max(key)} (GsrGeometry::status)
 struct GsrKeyBias { uint32_t min, culled; };  // culled = value that stands for 0xFFFFFFFF keys = (max - min) + 1
