@@ -343,19 +343,18 @@ def step_stats(ms):
 
 def valu_issue_fraction(stage, workload, kernel_ms=None):
     """Fraction of the chip's vector-ALU issue roof the kernel reaches, from the committed PMC summary (tools/profile_run.sh ->
-    tools/pmc_summary.py): roof time = sum over instruction classes of (count from SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F32 and
-    SQ_INSTS_VALU) x (the time one SIMD needs per instruction of the class, measured on this chip with tools/valu_probe.hip at
-    4-8 waves per SIMD -- profiles/r3_valu_probe.txt: plain adds / multiplies 1.1-1.2 ns, FMAs 1.6, compares / selects 1.85,
-    packed two-pixel ops 1.9-2.1, transcendentals 3.4), divided by 1024 SIMDs and by the kernel's duration.  Time-domain on both
-    sides, so no clock estimate enters; the counters were checked against kernels of known instruction counts
-    (profiles/r3_pmc_calibration.txt).  With kernel_ms given (this run's own duration of the kernel) the fraction is taken
-    against it, else against the duration recorded with the counters."""
+    tools/pmc_summary.py): roof time = the kernel's wave64 VALU instructions (SQ_INSTS_VALU, exact: checked against kernels of
+    known instruction counts, profiles/r3_pmc_calibration.txt) / the rate the chip SUSTAINS on a synthetic, dependency-free
+    stream with the same instruction-class mix at the same occupancy (tools/valu_probe.hip "backward blend class mix": 588 G
+    instr/s at 4 waves per SIMD; the class mix from SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F32; profiles/r3_valu_probe.txt), divided by
+    the kernel's duration.  Time-domain on both sides, so no clock estimate enters.  With kernel_ms given (this run's own duration
+    of the kernel) the fraction is taken against it, else against the duration recorded with the counters."""
     try:
         e = _pmc_entry(stage, workload)
         ms = kernel_ms if kernel_ms else e["kernel_ms"]
         return dict(frac=round(e["valu_roof_ms"] / ms, 3), roof_ms=round(e["valu_roof_ms"], 4), kernel_ms=round(ms, 4),
                     valu_insts=int(e["SQ_INSTS_VALU"]), class_counts={k: int(v) for k, v in e.get("valu_class_counts", {}).items()},
-                    avg_waves_per_simd=round(e.get("avg_waves_per_simd", 0.0), 2), model="per-class costs from tools/valu_probe.hip",
+                    avg_waves_per_simd=round(e.get("avg_waves_per_simd", 0.0), 2), model=e.get("valu_roof_model", "additive per-class costs"),
                     source=os.path.basename(PMC_SUMMARY))
     except (OSError, KeyError, ValueError, ZeroDivisionError):
         return None

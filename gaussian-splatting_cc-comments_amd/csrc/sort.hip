@@ -37,7 +37,9 @@
 // ... and 32 for the largest sorts: re-swept with the LDS ranking, 12 / 16 / 24 / 32 items -> 0.124 / 0.126 / 0.136 / 0.150 ms at
 // R = 9.2M (C3) but 1.30 / 1.17 / 1.12 / 1.07 ms at R = 71M (C5), where the longer digit runs of an 8 192-element block pay
 #define GSR_SORT_ITEMS_HUGE 32
+#ifndef GSR_SORT_HUGE_N
 #define GSR_SORT_HUGE_N (32u << 20)
+#endif
 #ifndef GSR_WALK_ROWS
 #define GSR_WALK_ROWS 8    // rows of the offset tables a wave keeps in flight (one uint4 per lane each)
 #endif

@@ -20,7 +20,15 @@ SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F32 count one per instruction, packed or not (
     valu_roof_frac = valu_roof_ms / kernel_ms     (kernel_ms of the un-profiled run)
 with the class counts from the counters and "other" = SQ_INSTS_VALU minus the four classes (compares, selects, moves, min/max,
 cross-lane moves: 1.85 ns).  The counters cannot tell a packed instruction from a plain one, so the share of packed (and, for
-adds, DPP) instructions per class is a per-kernel constant read off the ISA of its loops (VALU_MIX below)."""
+adds, DPP) instructions per class is a per-kernel constant read off the ISA of its loops (VALU_MIX below).
+
+That additive model is PESSIMISTIC for a mixed stream: waves with cheap and expensive instructions overlap better than the sum of
+their single-kind costs (at C5, where the forward blend has no tail to speak of, it read 1.12).  For the two blend kernels the roof
+is therefore measured, not composed: the probe runs a dependency-free stream with the SAME class mix as the kernel (kinds
+"forward / backward blend class mix": 22 resp. 25 instructions in the proportions the class counters report) and the chip's
+sustained rate on it, at the kernel's occupancy, is the roof:
+    valu_roof_ms = SQ_INSTS_VALU / MIX_RATE[kernel],   forward 779 G instr/s (6 waves per SIMD), backward 588 (4 waves per SIMD)
+(profiles/r3_valu_probe.txt).  The additive figure is kept beside it as valu_roof_ms_additive."""
 import collections
 import csv
 import glob
@@ -78,6 +86,8 @@ COST = dict(add=1024 / 904.0, add_dpp=1024 / 555.0, pk_add=1024 / 534.0, mul=102
 # per-tile work counters of tools/tile_clock.py (profiles/r3_tile_clock_c3_uniform.txt): the backward blend evaluates its pixel
 # pairs with packed instructions and reduces with plain and DPP adds; nothing else on the path uses packed arithmetic
 VALU_MIX = {"gsr_render_backward_wave_kernel": dict(pk_add=0.39, dpp_add=0.21, pk_mul=0.88, pk_fma=0.93)}
+# chip-wide sustained rate (G wave64 instructions / s) of the probe's class-mix streams at the kernels' occupancies
+MIX_RATE = {"gsr_render_forward_wave_kernel": 779.0, "gsr_render_backward_wave_kernel": 588.0}
 for k, e in out.items():
     if all(n in e for n in ("SQ_INSTS_VALU", "SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_FMA_F32")) and "kernel_ms" in e:
         mix = VALU_MIX.get(k.split("<")[0], {})
@@ -87,7 +97,10 @@ for k, e in out.items():
         pa, da, pm, pf = mix.get("pk_add", 0.0), mix.get("dpp_add", 0.0), mix.get("pk_mul", 0.0), mix.get("pk_fma", 0.0)
         ns = (a * (pa * COST["pk_add"] + da * COST["add_dpp"] + (1 - pa - da) * COST["add"]) + m * (pm * COST["pk_mul"] + (1 - pm) * COST["mul"]) +
               f * (pf * COST["pk_fma"] + (1 - pf) * COST["fma"]) + t * COST["trans"] + other * COST["other"])
-        e["valu_roof_ms"] = ns / 1024.0 * 1e-6
+        e["valu_roof_ms_additive"] = ns / 1024.0 * 1e-6
+        rate = MIX_RATE.get(k.split("<")[0])
+        e["valu_roof_ms"] = e["SQ_INSTS_VALU"] / (rate * 1e9) * 1e3 if rate else e["valu_roof_ms_additive"]
+        e["valu_roof_model"] = "measured rate of a synthetic stream of the kernel's class mix" if rate else "additive per-class costs"
         e["valu_roof_frac"] = e["valu_roof_ms"] / e["kernel_ms"]
         e["valu_class_counts"] = dict(add=a, mul=m, fma=f, trans=t, other=other)
 out["_workload"] = sys.argv[3] if len(sys.argv) > 3 else "C3"

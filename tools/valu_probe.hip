@@ -12,8 +12,8 @@
 typedef float v2f __attribute__((ext_vector_type(2)));
 #define ITERS 2048
 
-enum { K_FMA, K_PKFMA, K_EXP, K_RCP, K_MIX, K_CNDMASK, K_DPP, K_CNDMASK_S, K_CMP_CND, K_PKMUL, K_CMP, K_CMP_S, K_MOV, K_MAX, K_PERM32, K_MUL2, K_FMAC2, K_BLEND, K_ADD2, K_PKADD, K_NKINDS };
-static const char* KNAME[] = {"v_fma_f32", "v_pk_fma_f32", "v_exp_f32", "v_rcp_f32", "7 v_fma + 1 v_exp", "v_cndmask_b32 vcc", "v_add_f32 dpp", "v_cndmask_b32 sgpr", "v_cmp + v_cndmask", "v_pk_mul_f32", "v_cmp_gt_f32 vcc", "v_cmp_gt_f32 sgpr", "v_mov_b32", "v_max_f32", "v_permlane32_swap", "v_mul_f32_e32", "v_fmac_f32_e32", "forward-blend mix", "v_add_f32_e32", "v_pk_add_f32"};
+enum { K_FMA, K_PKFMA, K_EXP, K_RCP, K_MIX, K_CNDMASK, K_DPP, K_CNDMASK_S, K_CMP_CND, K_PKMUL, K_CMP, K_CMP_S, K_MOV, K_MAX, K_PERM32, K_MUL2, K_FMAC2, K_BLEND, K_ADD2, K_PKADD, K_FWDMIX, K_BWDMIX, K_NKINDS };
+static const char* KNAME[] = {"v_fma_f32", "v_pk_fma_f32", "v_exp_f32", "v_rcp_f32", "7 v_fma + 1 v_exp", "v_cndmask_b32 vcc", "v_add_f32 dpp", "v_cndmask_b32 sgpr", "v_cmp + v_cndmask", "v_pk_mul_f32", "v_cmp_gt_f32 vcc", "v_cmp_gt_f32 sgpr", "v_mov_b32", "v_max_f32", "v_permlane32_swap", "v_mul_f32_e32", "v_fmac_f32_e32", "forward-blend mix", "v_add_f32_e32", "v_pk_add_f32", "forward blend class mix", "backward blend class mix"};
 
 template <int KIND>
 __global__ void __launch_bounds__(1024) probe(float* out, unsigned long long* stamps, unsigned long long* sched)
@@ -24,7 +24,7 @@ __global__ void __launch_bounds__(1024) probe(float* out, unsigned long long* st
 #pragma unroll
 	for (int i = 0; i < 8; i++) { a[i] = 1.0f + threadIdx.x * 1e-3f + i; p[i] = v2f{a[i], a[i] + 0.5f}; }
 	const float b = 0.999f, c = 1e-3f, binv = 1.0f / 0.999f;
-	const v2f b2 = {b, b}, c2 = {c, c};
+	const v2f b2 = {b, b}, c2 = {c, c}, binv2 = {binv, binv};
 	const unsigned long long smask = __builtin_amdgcn_ballot_w64(threadIdx.x & 1);
 	unsigned long long sm[4] = {0, 0, 0, 0};
 	const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
@@ -50,6 +50,31 @@ __global__ void __launch_bounds__(1024) probe(float* out, unsigned long long* st
 				else if (KIND == K_MAX) asm volatile("v_max_f32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
 				else if (KIND == K_PERM32) asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(a[i]), "+v"(a[(i + 1) & 7]));
 				else if (KIND == K_MUL2) { if (u & 1) asm volatile("v_mul_f32_e32 %0, %1, %0" : "+v"(a[i]) : "v"(b)); else asm volatile("v_mul_f32_e32 %0, %1, %0" : "+v"(a[i]) : "v"(binv)); }
+				else if (KIND == K_FWDMIX) {
+					// 22 instructions in the class proportions the counters report for gsr_render_forward_wave_kernel (profiles/r3_pmc_summary.json):
+					// 4 add / sub, 7 mul, 3 fmac, 1 exp, 7 "other" (1 min, 3 compares into SGPR pairs, 3 selects by SGPR masks)
+					asm volatile("v_sub_f32_e32 %0, %0, %2\n\tv_mul_f32_e32 %0, %1, %0\n\tv_mul_f32_e32 %0, %3, %0\n\tv_add_f32_e32 %0, %2, %0\n\t"
+					             "v_mul_f32_e32 %0, %1, %0\n\tv_sub_f32_e32 %0, %0, %2\n\tv_mul_f32_e32 %0, %3, %0\n\tv_exp_f32_e32 %0, %0\n\t"
+					             "v_mul_f32_e32 %0, %1, %0\n\tv_min_f32_e32 %0, %1, %0\n\tv_sub_f32_e32 %0, %0, %2\n\tv_mul_f32_e32 %0, %3, %0"
+					             : "+v"(a[i]) : "v"(b), "v"(c), "v"(binv));
+					asm volatile("v_cmp_gt_f32 %0, %1, %2\n\tv_cmp_lt_f32 %0, %1, %3\n\tv_cmp_gt_f32 %0, %2, %1\n\tv_mul_f32_e32 %1, %2, %1\n\t"
+					             "v_cndmask_b32 %1, %1, %2, %4\n\tv_fmac_f32_e32 %1, %2, %3\n\tv_fmac_f32_e32 %1, %3, %2\n\tv_fmac_f32_e32 %1, %2, %3\n\t"
+					             "v_cndmask_b32 %1, %1, %3, %4\n\tv_cndmask_b32 %1, %2, %1, %4"
+					             : "=&s"(sm[i & 3]), "+v"(a[i]) : "v"(b), "v"(c), "s"(smask));
+				} else if (KIND == K_BWDMIX) {
+					// 25 instructions in the class proportions of gsr_render_backward_wave_kernel: 7 adds (3 packed, 2 plain, 2 DPP), 6 multiplies
+					// (5 packed), 3 packed FMAs, 1 transcendental, 8 "other" (3 compares, 3 selects, 1 min, 1 move)
+					asm volatile("v_pk_add_f32 %0, %0, %2\n\tv_pk_mul_f32 %0, %0, %1\n\tv_pk_mul_f32 %0, %0, %3\n\tv_pk_add_f32 %0, %0, %2\n\t"
+					             "v_pk_mul_f32 %0, %0, %1\n\tv_pk_fma_f32 %0, %0, %3, %2\n\tv_pk_mul_f32 %0, %0, %1\n\tv_pk_fma_f32 %0, %0, %3, %2\n\t"
+					             "v_pk_add_f32 %0, %0, %2\n\tv_pk_mul_f32 %0, %0, %3\n\tv_pk_fma_f32 %0, %0, %1, %2"
+					             : "+v"(p[i]) : "v"(b2), "v"(c2), "v"(binv2));
+					asm volatile("v_add_f32_e32 %1, %3, %1\n\tv_rcp_f32_e32 %1, %1\n\tv_mul_f32_e32 %1, %2, %1\n\tv_add_f32_e32 %1, %3, %1\n\t"
+					             "v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\tv_min_f32_e32 %1, %2, %1\n\t"
+					             "v_cmp_gt_f32 %0, %1, %2\n\tv_cmp_lt_f32 %0, %1, %3\n\tv_cmp_gt_f32 %0, %2, %1\n\t"
+					             "v_cndmask_b32 %1, %1, %2, %4\n\tv_cndmask_b32 %1, %1, %3, %4\n\tv_cndmask_b32 %1, %2, %1, %4\n\t"
+					             "v_add_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\tv_mov_b32_e32 %1, %1"
+					             : "=&s"(sm[i & 3]), "+v"(a[i]) : "v"(b), "v"(c), "s"(smask));
+				}
 				else if (KIND == K_ADD2) asm volatile("v_add_f32_e32 %0, %1, %0" : "+v"(a[i]) : "v"(c));
 				else if (KIND == K_PKADD) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(p[i]) : "v"(c2));
 				else if (KIND == K_FMAC2) asm volatile("v_fmac_f32_e32 %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
@@ -91,7 +116,7 @@ static void run(int w, float* out, unsigned long long* stamps, unsigned long lon
 	const int per_cu = w, threads = 256;
 	const int nwg = 256 * per_cu, nwaves = nwg * threads / 64;
 	const size_t lds = (size_t)(160 * 1024) / (w + 1) + 1024;
-	const double per_wave_instr = (KIND == K_BLEND) ? 8.0 : (KIND == K_CMP_CND ? 2.0 : 1.0);
+	const double per_wave_instr = (KIND == K_BLEND) ? 8.0 : (KIND == K_FWDMIX ? 22.0 : (KIND == K_BWDMIX ? 25.0 : (KIND == K_CMP_CND ? 2.0 : 1.0)));
 	hipFuncSetAttribute((const void*)probe<KIND>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 	hipEvent_t e0, e1;
 	hipEventCreate(&e0); hipEventCreate(&e1);
@@ -146,8 +171,8 @@ int main()
 	unsigned long long* sched;
 	hipMalloc(&sched, 8192 * 32);
 	unsigned long long* h = (unsigned long long*)malloc(8192 * 16);
-	const int ws[] = {1, 4, 5, 8};
-	for (int wi = 0; wi < 4; wi++) {
+	const int ws[] = {1, 4, 5, 6, 8};
+	for (int wi = 0; wi < 5; wi++) {
 		const int w = ws[wi];
 		run<K_FMA>(w, out, stamps, h, sched);
 		run<K_PKFMA>(w, out, stamps, h, sched);
@@ -169,6 +194,8 @@ int main()
 		run<K_BLEND>(w, out, stamps, h, sched);
 		run<K_ADD2>(w, out, stamps, h, sched);
 		run<K_PKADD>(w, out, stamps, h, sched);
+		run<K_FWDMIX>(w, out, stamps, h, sched);
+		run<K_BWDMIX>(w, out, stamps, h, sched);
 	}
 	return 0;
 }
