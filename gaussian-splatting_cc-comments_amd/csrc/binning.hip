@@ -277,7 +277,7 @@ extern "C" int gsr_debug_backward_key(uint32_t* key) { g_debug_backward_key = ke
 // first, at most max_split tiles; the entries [ntiles + 3 nsplit, ntiles + 3 max_split) are marked empty.
 __global__ void __launch_bounds__(1024) gsr_tile_order_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ tile_max_contrib,
                                                               uint32_t ntiles, uint32_t* __restrict__ order, int split_bin_max, uint32_t max_split,
-                                                              uint32_t* __restrict__ tile_max_contrib_out, uint32_t seg_budget)
+                                                              uint32_t* __restrict__ tile_max_contrib_out, uint32_t seg_budget, int allow_cut)
 {
 	__shared__ uint32_t bin[GSR_ORDER_BINS];
 	__shared__ uint32_t wsum[1024 / 64];
@@ -301,7 +301,7 @@ __global__ void __launch_bounds__(1024) gsr_tile_order_kernel(const uint2* __res
 	// (T, C) checkpoints every GSR_CKPT_STRIDE instances, so a wave can start in the middle of the list, and every segment
 	// writes the gradient slots of its own instances only.  All segment entries go to the front of the list (they belong to the
 	// heaviest tiles); if they do not fit the budget nothing is cut.
-	if (seg_budget) {   // entries the cut tiles would take, for the four coarseness levels (work values: the registers above)
+	if (seg_budget && allow_cut) {   // entries the cut tiles would take, for the four coarseness levels (work values: the registers above)
 		uint32_t my_items[4] = {0u, 0u, 0u, 0u};
 		auto count = [&](uint32_t w) {
 			if (w < 2 * GSR_CKPT_STRIDE) return;   // (almost every tile)
@@ -342,7 +342,7 @@ __global__ void __launch_bounds__(1024) gsr_tile_order_kernel(const uint2* __res
 	s_incl[threadIdx.x] = incl;
 	__syncthreads();
 	uint32_t coarse = 0u, nheavy = 0u, front = 0u;
-	if (seg_budget)
+	if (seg_budget && allow_cut)
 		for (int f = 0; f < 4 && !coarse; f++) {
 			const uint32_t tiles_f = s_incl[GSR_ORDER_BINS - 1 - ((1u << f) + 1u) * (GSR_CKPT_STRIDE / 16)];
 			if (s_seg_items[f] != 0u && s_seg_items[f] - tiles_f <= seg_budget) { coarse = 1u << f; nheavy = tiles_f; front = s_seg_items[f]; }
@@ -365,7 +365,8 @@ __global__ void __launch_bounds__(1024) gsr_tile_order_kernel(const uint2* __res
 			order[3 * nsplit + q] = t;
 		}
 	};
-	if (split_bin_max >= 0)
+	// the blend kernels are launched over the whole list, split or not: what is not used is marked empty
+	if (max_split)
 		for (uint32_t e = ntiles + 3 * nsplit + threadIdx.x; e < ntiles + 3 * max_split; e += 1024) order[e] = 0xFFFFFFFFu;
 	if (seg_budget)
 		for (uint32_t e = ntiles + (front - nheavy) + threadIdx.x; e < ntiles + seg_budget; e += 1024) order[e] = 0xFFFFFFFFu;
@@ -400,19 +401,19 @@ void gsr_launch_tile_order(GsrImage img, int ntiles, bool backward, int64_t num_
 	// walked is not known before the forward has run; on the low-opacity blob scene the tiles that set the span were walked
 	// 2 400 - 3 300 deep whatever their length, 2 - 25 x the mean)
 	int split_bin_max = -1;
-	uint32_t max_split = 0;
-	if (!backward && split && ntiles < (1 << 28)) {
-		max_split = gsr_tile_order_max_split(ntiles);
+	const uint32_t max_split = backward ? 0u : gsr_tile_order_max_split(ntiles);   // the forward's list always has this room
+	if (!backward && split && max_split) {
 		const int64_t mean = num_rendered / (ntiles > 0 ? ntiles : 1);
 		const int64_t heavy = mean * 2 > 1024 ? mean * 2 : 1024;
-		split_bin_max = max_split ? GSR_ORDER_BINS - 1 - (int)((heavy + 15) / 16 < GSR_ORDER_BINS - 1 ? (heavy + 15) / 16 : GSR_ORDER_BINS - 1) : -1;
+		split_bin_max = GSR_ORDER_BINS - 1 - (int)((heavy + 15) / 16 < GSR_ORDER_BINS - 1 ? (heavy + 15) / 16 : GSR_ORDER_BINS - 1);
 	}
-	uint32_t seg_budget = (backward && split && ntiles < (1 << 28)) ? gsr_tile_order_max_segments(ntiles) : 0u;
+	const uint32_t seg_budget = backward ? gsr_tile_order_max_segments(ntiles) : 0u;   // the backward's list always has this room
+	int allow_cut = split ? 1 : 0;
 #ifdef GSR_TILE_CLOCK
-	if (!ranges) seg_budget = 0u;
+	if (!ranges) allow_cut = 0;
 #endif
 	hipLaunchKernelGGL(gsr_tile_order_kernel, dim3(1), dim3(1024), 0, s, ranges, key, (uint32_t)ntiles, img.tile_order, split_bin_max, max_split,
-	                   img.tile_max_contrib, seg_budget);
+	                   img.tile_max_contrib, seg_budget, allow_cut);
 }
 
 void gsr_launch_tile_ranges(const void* tile_keys, int key_bytes, int64_t R, uint2* ranges, int ntiles, uint32_t* valid, hipStream_t s)

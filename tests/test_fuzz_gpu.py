@@ -79,3 +79,45 @@ def test_tiny_and_degenerate_sizes_match_oracle(P, W, H, D):
     check_forward(h, o, cam)
     if o["num_rendered"] > 0:
         check_grads(h, o, dpix, ["dL_dmeans3D", "dL_dmeans2D", "dL_dopacity", "dL_dsh", "dL_dscales", "dL_drotations"])
+
+
+@pytest.mark.parametrize("seed", list(range(6)))
+def test_random_heavy_tile_scenes_match_oracle_split_or_not(seed):
+    """Randomised scenes with a dense, mostly low-opacity clump: a few tiles carry lists many times the mean and are walked
+    thousands of instances deep -- the scenes on which heavy tiles are dispatched as band waves (forward) and depth segments
+    (backward).  Image sizes include partial edge tiles and images of fewer than 64 tiles (no split possible); the clump's
+    size and opacity decide how many tiles are split, how deep they are cut and how coarse the segments get.  Against the
+    oracle with the usual bars; the forward must also be bit-identical to the run with GSR_DEBUG_NO_SPLIT."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from diff_gaussian_rasterization import GaussianRasterizer
+    from diff_gaussian_rasterization import _C
+    r = np.random.default_rng(7000 + seed)
+    W, H = [(330, 210), (97, 61), (500, 140), (257, 259), (640, 360), (120, 300)][seed]
+    D = int(r.integers(0, 4))
+    P = int(r.integers(20_000, 70_000))
+    scene = gsr_scene.make_scene(P, float(r.uniform(-4.2, -3.2)), sh_degree=D, seed=900 + seed)
+    g = torch.Generator().manual_seed(50 + seed)
+    nb = int(P * float(r.uniform(0.5, 0.85)))
+    means = scene.means3D.clone()
+    centre = torch.tensor(r.uniform(-0.6, 0.6, 3), dtype=torch.float32)
+    means[:nb] = centre + torch.randn(nb, 3, generator=g) * torch.tensor([float(r.uniform(0.05, 0.3)), float(r.uniform(0.05, 0.2)), 0.3])
+    opac = scene.opacities.clone()
+    opac[:nb] = torch.sigmoid(torch.randn(nb, 1, generator=g) + float(r.uniform(-4.5, -2.0)))
+    scene = scene._replace(means3D=means.contiguous(), opacities=opac.contiguous())
+    cam = gsr_scene.make_camera(W, H, fovx=float(r.uniform(0.7, 1.3)))
+    o = util.oracle_forward(scene, cam, D)
+    dpix = util.fragile_free_dpix(o, cam, seed=seed)
+    h = util.hip_forward_backward(scene, cam, D, dpix)
+    check_forward(h, o, cam)
+    check_grads(h, o, dpix, ["dL_dmeans3D", "dL_dmeans2D", "dL_dopacity", "dL_dsh", "dL_dscales", "dL_drotations"], label=f"heavy_fuzz_{seed}")
+    # the unsplit run: same image and state bit for bit
+    dev = torch.device("cuda:0")
+    st = util.hip_settings(scene, cam, D, dev)._replace(debug=_C.DEBUG_NO_SPLIT)
+    t = {k: getattr(scene, k).to(dev) for k in ("means3D", "shs", "opacities", "scales", "rotations")}
+    with torch.no_grad():
+        color, radii = GaussianRasterizer(st)(means2D=torch.zeros_like(t["means3D"]), **t)
+    assert np.array_equal(color.cpu().numpy(), h["color"]) and np.array_equal(radii.cpu().numpy(), h["radii"])
+    T = ((W + 15) // 16) * ((H + 15) // 16)
+    lens = (h["ranges"][:, 1].astype(np.int64) - h["ranges"][:, 0])
+    print(f"seed {seed}: {W}x{H} ({T} tiles) D{D} P{P} R={o['num_rendered']} longest list {int(lens.max())} mean {int(lens.mean())}")
