@@ -55,6 +55,7 @@ __global__ void __launch_bounds__(64 * GSR_WAVES_PER_WG) __attribute__((amdgpu_w
 	const uint32_t* plist = point_list + range.x;
 	// a heavy tile leaves depth checkpoints for the backward (gsr_internal.h GSR_CKPT_STRIDE): wave-uniform
 	const bool heavy = n >= 2 * GSR_CKPT_STRIDE;
+	bool walked_deep = false;   // a checkpoint was stored: only then can the backward cut this tile, and only then is final_C read
 
 	float Tout[GSR_PIX_PER_LANE], C0[GSR_PIX_PER_LANE], C1[GSR_PIX_PER_LANE], C2[GSR_PIX_PER_LANE];
 	float pfy[GSR_PIX_PER_LANE];
@@ -84,6 +85,7 @@ __global__ void __launch_bounds__(64 * GSR_WAVES_PER_WG) __attribute__((amdgpu_w
 		if ((alive[0] | alive[1] | alive[2] | alive[3]) == 0ull) break;
 		if (heavy && base != 0 && (base & (GSR_CKPT_STRIDE - 1)) == 0) {
 			// every pixel's state BEFORE the instance at position `base` (a finished pixel's state is its final one)
+			walked_deep = true;
 			float4* ck = checkpoints + ((size_t)(range.x + (uint32_t)base) / GSR_CKPT_STRIDE) * 256 + lane;
 #pragma unroll
 			for (int k = 0; k < GSR_PIX_PER_LANE; k++)
@@ -163,7 +165,7 @@ __global__ void __launch_bounds__(64 * GSR_WAVES_PER_WG) __attribute__((amdgpu_w
 			out_color[pix_id] = C0[k] + Tout[k] * bg0;
 			out_color[plane + pix_id] = C1[k] + Tout[k] * bg1;
 			out_color[2 * plane + pix_id] = C2[k] + Tout[k] * bg2;
-			if (heavy) { final_C[pix_id] = C0[k]; final_C[plane + pix_id] = C1[k]; final_C[2 * plane + pix_id] = C2[k]; }
+			if (walked_deep) { final_C[pix_id] = C0[k]; final_C[plane + pix_id] = C1[k]; final_C[2 * plane + pix_id] = C2[k]; }
 			m = max(m, last[k]);
 		}
 	}
