@@ -381,9 +381,14 @@ def main():
         dev = torch.device("cuda", local_rank)
         torch.cuda.set_device(dev)  # before any collective: RCCL binds the communicator to the current device
     phase = {"now": "start"}
-    if world > 1:
+    # GSR_BENCH_FORCE_GROUP=1 (tests): form the process group and take the view-parallel step even with ONE rank -- on a
+    # one-GPU box that is the only way to run this code over RCCL (two ranks cannot share a device under RCCL)
+    grouped = world > 1 or os.environ.get("GSR_BENCH_FORCE_GROUP") == "1"
+    if grouped:
         import datetime
         import threading
+        if env_world is None:   # forced group without a launcher: the rendezvous of a one-rank group
+            os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
 
         def _deadline():
             print(f"bench.py rank {rank}: --deadline-s {args.deadline_s:.0f} exceeded during '{phase['now']}'; exiting", file=sys.stderr, flush=True)
@@ -405,22 +410,23 @@ def main():
                   f"{args.collective_timeout_s:.0f} s: {ex!r}", file=sys.stderr, flush=True)
             sys.exit(3)
     try:
-        run_rank(args, rank, world, dev, phase)
+        run_rank(args, rank, world, dev, phase, grouped)
     except Exception as ex:  # noqa: BLE001
-        if world > 1:   # a failed or timed-out collective: say so and leave with a code; the launcher stops the other ranks
+        if grouped:   # a failed or timed-out collective: say so and leave with a code; the launcher stops the other ranks
             import traceback
             traceback.print_exc()
             print(f"bench.py rank {rank}: failed during '{phase['now']}': {ex!r}", file=sys.stderr, flush=True)
             os._exit(3)   # not sys.exit: destroy_process_group() on a broken communicator can itself block
         raise
-    if world > 1:
+    if grouped:
         phase["now"] = "destroy_process_group"
         dist.destroy_process_group()
 
 
-def run_rank(args, rank, world, dev, phase=None):
+def run_rank(args, rank, world, dev, phase=None, grouped=None):
     import view_parallel
     phase = phase if phase is not None else {}
+    grouped = (world > 1) if grouped is None else grouped
     kviews = max(1, int(args.views_per_rank))
     P, W, H, D, mu = gsr_scene.CONFIGS[args.config]
     M = (D + 1) ** 2
@@ -428,7 +434,7 @@ def run_rank(args, rank, world, dev, phase=None):
 
     def barrier():
         sync()
-        if world > 1:
+        if grouped:
             dist.barrier()
 
     if args.dry_run:
@@ -476,8 +482,8 @@ def run_rank(args, rank, world, dev, phase=None):
         dpix = dpixs[0]
         state = {}
         ex = {m: view_parallel.GradientExchange(P, M, dev, sh_mode=m, parts=args.parts) for m in ("compact", "allreduce")} \
-            if (world > 1 and kviews == 1) else {}
-        bucket = view_parallel.GradientBucket(list(params.values())) if (world > 1 and kviews > 1) else None
+            if (grouped and kviews == 1) else {}
+        bucket = view_parallel.GradientBucket(list(params.values())) if (grouped and kviews > 1) else None
 
         def make_step(mode):
             def step():
@@ -485,7 +491,7 @@ def run_rank(args, rank, world, dev, phase=None):
                     p.grad = None
                 for rast, st, dp in zip(rasterizers, all_settings, dpixs):
                     means2D = torch.zeros_like(params["means3D"], requires_grad=True)  # gaussian_renderer/__init__.py:37
-                    if world > 1 and kviews == 1:
+                    if grouped and kviews == 1:
                         # view-parallel: this rank's view; the backward exchanges the 59 floats/Gaussian of parameter
                         # gradients part by part (view_parallel.GradientExchange) and returns their sum over the ranks
                         color, radii = view_parallel.rasterize_view_parallel(params["means3D"], means2D, params["shs"], params["opacities"],
@@ -524,7 +530,7 @@ def run_rank(args, rank, world, dev, phase=None):
             per = [(b - a) * 1e3 for a, b in zip(marks[:-1], marks[1:])]
         else:
             per = [a.elapsed_time(b) for a, b in zip(marks[:-1], marks[1:])]
-        if world > 1:
+        if grouped:
             tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             elapsed = float(tmax.item())
@@ -567,7 +573,7 @@ def run_rank(args, rank, world, dev, phase=None):
         ktimes = _C.profile_end(capacity=64 * table_steps)
     alt = None
     phase["now"] = "per-kernel table / alternative exchange mode"
-    if world > 1 and (args.dry_run or kviews == 1):
+    if grouped and (args.dry_run or kviews == 1):
         other = "allreduce" if mode == "compact" else "compact"
         for _ in range(max(1, args.warmup)):
             steps[other]()
@@ -587,9 +593,9 @@ def run_rank(args, rank, world, dev, phase=None):
                                 "first ~20 steps of a fresh process run up to 7 % slower); --settle-steps 0 disables"))
     if alt is not None:
         out["alt_exchange"] = alt
-    if world > 1 and kviews == 1:
+    if grouped and kviews == 1:
         parallelism = f"view-parallel x{world}, one view per rank, SH gradient exchange: {mode}, backward in {args.parts} parts"
-    elif world > 1:
+    elif grouped:
         parallelism = (f"view-parallel x{world}, {kviews} views per rank and step (local gradient accumulation), one flat all-reduce of "
                        "59 floats/Gaussian per step")
     else:

@@ -371,11 +371,17 @@ def test_bench_gpus_2_on_one_gpu_over_gloo():
     assert d["data"] == "synthetic" and d["kernels"]["render_backward"]["ms"] > 0
 
 
-def _vp_worker(rank, world, port, sh_mode, out_dir):
+def _vp_worker(rank, world, port, sh_mode, out_dir, backend="gloo"):
+    import datetime
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if backend == "nccl":
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0), timeout=datetime.timedelta(seconds=120))
+    else:
+        dist.init_process_group(backend, rank=rank, world_size=world)
     try:
         import view_parallel
         from diff_gaussian_rasterization import GaussianRasterizer
@@ -430,3 +436,37 @@ def test_view_parallel_two_ranks_sum_the_gradients_of_two_views(sh_mode, tmp_pat
     s.close()
     mp.spawn(_vp_worker, args=(2, port, sh_mode, str(tmp_path)), nprocs=2, join=True)
     assert (tmp_path / "ok0").exists() and (tmp_path / "ok1").exists()
+
+
+@pytest.mark.parametrize("sh_mode", ["compact", "allreduce"])
+def test_view_parallel_step_over_rccl_one_rank(sh_mode, tmp_path):
+    """The view-parallel step with its collectives executed by RCCL (backend "nccl"): a ONE-rank communicator, which is all
+    a one-GPU box allows (RCCL refuses two ranks on one device) -- init with a finite timeout, the per-part all-gather /
+    all-reduce calls of GradientExchange with exactly the tensors, dtypes and shapes of the N-rank run, and the teardown.
+    With one rank the summed gradients are this view's own."""
+    _need_gpu()
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_vp_worker, args=(1, port, sh_mode, str(tmp_path), "nccl"), nprocs=1, join=True)
+    assert (tmp_path / "ok0").exists()
+
+
+def test_bench_view_parallel_path_over_rccl_one_rank():
+    """`bench.py` on its N > 1 code path -- process group over RCCL, rasterize_view_parallel with both exchange modes, the
+    max-over-ranks all-reduce of the timing -- forced on with one rank (GSR_BENCH_FORCE_GROUP=1)."""
+    _need_gpu()
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["GSR_BENCH_FORCE_GROUP"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--config", "C1", "--steps", "3", "--warmup", "1",
+                        "--settle-steps", "2", "--no-extras", "--no-cpu-baseline", "--collective-timeout-s", "120", "--deadline-s", "400"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["value"] > 0 and "view-parallel" in d["config"]["parallelism"]
+    assert d["alt_exchange"]["mode"] == "allreduce" and d["alt_exchange"]["value"] > 0
