@@ -70,6 +70,9 @@ def algorithmic_bytes(P, V, R, Rp, N, T, M):
         "duplicate_keys": 20 * P + 12 * R,
         "sort": 24 * R,
         "tile_ranges": 8 * R + 16 * T,
+        # the column-pair binning (csrc/tilebin.hip) replaces the three stages above as a whole: "binning" = its three
+        # kernels together, priced at the SURVEY's bytes for the stages they replace
+        "binning": (20 * P + 12 * R) + 24 * R + (8 * R + 16 * T),
         "render_forward": 8 * T + 40 * Rp + 20 * N,
     }
     bwd = {
@@ -644,8 +647,15 @@ def run_rank(args, rank, world, dev, phase=None, grouped=None):
         kern[name] = dict(ms=round(avg, 4), launches=len(v), algorithmic_bytes=allb.get(name),
                           GBps=round(allb[name] / (avg * 1e-3) / 1e9, 1) if allb.get(name) and avg > 0 else None,
                           hbm_frac=round(allb[name] / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 3) if allb.get(name) and avg > 0 else None)
-    step_bytes = sum(fwd_b.values()) + sum(bwd_b.values())
-    dom = max(kern, key=lambda k: kern[k]["ms"]) if kern else None
+    tb = [kern[n]["ms"] for n in ("col_scatter", "row_hist", "row_scatter") if n in kern]
+    if len(tb) == 3:
+        ms = sum(tb)
+        kern["binning"] = dict(ms=round(ms, 4), launches=None, algorithmic_bytes=allb["binning"], GBps=round(allb["binning"] / (ms * 1e-3) / 1e9, 1),
+                               hbm_frac=round(allb["binning"] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 3),
+                               note="col_scatter + row_hist + row_scatter = duplicateWithKeys + SortPairs (tile bits) + identifyTileRanges of the "
+                                    "reference, against SURVEY 8(d)'s algorithmic bytes of those three stages")
+    step_bytes = sum(v for k, v in fwd_b.items() if k != "binning") + sum(bwd_b.values())
+    dom = max((k for k in kern if k != "binning"), key=lambda k: kern[k]["ms"]) if kern else None
     roofline = None
     if dom:
         if dom == DOMINANT_STAGE and dom_times:   # its launches inside the timed region

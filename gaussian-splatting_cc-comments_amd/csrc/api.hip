@@ -177,6 +177,7 @@ extern "C" int gsr_geometry_layout_of(int P, gsr_geometry_layout* o)
 	o->status = off;         off = gsr_align_up(off + GSR_STATUS_WORDS * 4);
 	o->scan_temp = off;      off = gsr_align_up(off + gsr_align_up(nb * 4));
 	o->sort_table = off;     off = gsr_align_up(off + gsr_radix_table_bytes(n));
+	o->col_table = off;      off = gsr_align_up(off + gsr_tilebin_col_table_bytes(n));
 	o->total = off;
 	return GSR_OK;
 }
@@ -209,10 +210,14 @@ extern "C" int gsr_binning_layout_of(int P, int64_t R, int W, int H, gsr_binning
 	o->point_list_alt = off; off = gsr_align_up(off + n * 4);
 	o->tile_keys = off;      off = gsr_align_up(off + n * 4);
 	o->tile_keys_alt = off;  off = gsr_align_up(off + n * 4);
-	o->sort_table = off;     off = gsr_align_up(off + gsr_radix_table_bytes(n));
+	{
+		const size_t a = gsr_radix_table_bytes(n), b = gsr_tilebin_row_table_bytes(n);   // tile sort (sort.hip) / pass 2 of tilebin.hip
+		o->sort_table = off; off = gsr_align_up(off + (a > b ? a : b));
+	}
 	o->checkpoints = off;    off = gsr_align_up(off + gsr_checkpoint_records(R) * 256 * sizeof(float4));
 	o->total = off;
 	o->tile_key_bytes = (size_t)gsr_tile_key_bytes(gsr_grid_x(W) * gsr_grid_y(H), n);
+	o->column_pairs = gsr_tilebin_applies(W, H) ? 1 : 0;
 	return GSR_OK;
 }
 
@@ -257,6 +262,7 @@ GsrGeometry gsr_geometry_view(void* blob, int P)
 	g.status = (uint32_t*)(b + l.status);
 	g.sorted_block_sums = (uint32_t*)(b + l.scan_temp);
 	g.sort_table = (void*)(b + l.sort_table);
+	g.col_table = (void*)(b + l.col_table);
 	return g;
 }
 
@@ -409,6 +415,7 @@ static int gsr_forward_preprocess_impl(int P, int D, int M, int width, int heigh
 	// launches are short and leave most of the chip idle, and is joined before this call's last kernel.  In line instead
 	// when every stage is being timed, with GSR_DEBUG_SYNC (a device sync follows every stage) and with GSR_DEBUG_SERIAL.
 	GsrThreadDevice& td = g_thread.dev[device];
+	const bool col_pairs = gsr_tilebin_applies(width, height) && !(debug & GSR_DEBUG_TILE_SORT);   // (stage 2 decides the same way)
 	const bool color = gsr_preprocess_needs_color(a);
 	bool beside = color && !(debug & (GSR_DEBUG_SYNC | GSR_DEBUG_SERIAL)) && !gsr_prof_records_all(s);
 	if (beside && !td.aux_stream) {
@@ -475,9 +482,11 @@ static int gsr_forward_preprocess_impl(int P, int D, int M, int width, int heigh
 	{
 		GsrProfScope p(s, "depth_sort");
 		gsr_radix_sort_passes(a.g.depth_keys, a.g.perm, a.g.depth_keys_alt, a.g.perm_alt, (size_t)P, 32, 4, 0, 3, a.g.sort_table, bias, 4, s);
-		// ... and so are the block sums over the three-pass result (the common case): the stream then holds work until the
-		// host, back from the wait below, has launched stage 2.  A fourth pass redoes them.
-		gsr_launch_sorted_block_sums(a.g, P, 1, s);
+		// ... and so are the block sums over the three-pass result (the common case) -- with them, for images the column-pair
+		// binning handles, the histogram of its first pass (tilebin.hip): the stream then holds work until the host, back from
+		// the wait below, has launched stage 2.  A fourth pass redoes them.
+		if (col_pairs) gsr_launch_tilebin_col_hist(a.g, P, 1, s);
+		else gsr_launch_sorted_block_sums(a.g, P, 1, s);
 	}
 	if ((rc = gsr_stage_done(s, debug, "depth_sort"))) return rc;
 	if ((rc = gsr_check_hip(hipEventSynchronize(ev), "hipEventSynchronize(num_rendered)"))) return rc;
@@ -500,7 +509,12 @@ static int gsr_forward_preprocess_impl(int P, int D, int M, int width, int heigh
 		GsrProfScope p(s, "depth_sort");
 		gsr_radix_sort_passes(a.g.depth_keys, a.g.perm, a.g.depth_keys_alt, a.g.perm_alt, (size_t)P, 32, 4, 3, 1, a.g.sort_table, bias, 4, s);
 		// three passes leave the order in (depth_keys_alt, perm_alt), four in (depth_keys, perm): recorded in status[2]
-		gsr_launch_sorted_block_sums(a.g, P, 0, s);   // (their prefix sums are taken by the key emission itself)
+		if (col_pairs) {   // the histogram's chunk sums were added to by the run over the three-pass order
+			if ((rc = gsr_check_hip(hipMemsetAsync(a.g.col_table, 0, gsr_tilebin_col_clear_words((size_t)P) * 4, s), "hipMemsetAsync(col_table)"))) return rc;
+			gsr_launch_tilebin_col_hist(a.g, P, 0, s);
+		} else {
+			gsr_launch_sorted_block_sums(a.g, P, 0, s);   // (their prefix sums are taken by the key emission itself)
+		}
 	}
 	return gsr_stage_done(s, debug, "depth_sort");
 }
@@ -554,34 +568,55 @@ extern "C" int gsr_forward_render(int P, int64_t R, int width, int height, const
 	int key_bytes = 4;
 	GsrBinning b;
 	memset(&b, 0, sizeof b);
-	if (R > 0) {
-		b = gsr_binning_view(binning, P, R, width, height);
-		const int bit = (int)gsr_get_higher_msb((uint32_t)ntiles);  // key bits above the depth word, rasterizer_impl.cu:355
-		// emit into whichever buffer pair makes the ping-pong sort finish in (tile_keys, point_list)
-		const bool even = gsr_radix_num_passes(bit) % 2 == 0;
-		uint32_t *k0 = even ? b.tile_keys : b.tile_keys_alt, *v0 = even ? b.point_list : b.point_list_alt;
-		uint32_t *k1 = even ? b.tile_keys_alt : b.tile_keys, *v1 = even ? b.point_list_alt : b.point_list;
-		key_bytes = gsr_tile_key_bytes(ntiles, (size_t)R);  // 16-bit tile ids whenever they fit: a quarter less traffic in emission, sort, ranges
+	const bool col_pairs = gsr_tilebin_applies(width, height) && !(debug & GSR_DEBUG_TILE_SORT);   // (as stage 1 decided)
+	if (R > 0) b = gsr_binning_view(binning, P, R, width, height);
+	if (R > 0 && col_pairs) {
+		// column pairs by tile column, their instances by tile row (tilebin.hip): point_list, ranges and the cleared validity
+		// bytes come out of the second pass; no per-instance key is ever stored
 		{
-			GsrProfScope p(s, "duplicate_keys");
-			gsr_launch_duplicate_keys(g, P, width, k0, key_bytes, v0, (uint32_t*)b.sort_table, gsr_radix_clear_words((size_t)R), s);
+			GsrProfScope p(s, "col_scatter");
+			gsr_launch_tilebin_col_scatter(g, P, b, R, s);
 		}
-		if ((rc = gsr_stage_done(s, debug, "duplicate_keys"))) return rc;
+		if ((rc = gsr_stage_done(s, debug, "col_scatter"))) return rc;
 		{
-			GsrProfScope p(s, "sort");
-			int in_first = 1;
-			gsr_radix_sort_u32(k0, v0, k1, v1, (size_t)R, bit, b.sort_table, &in_first, 0, key_bytes, s);  // chunk sums zeroed by duplicate_keys
+			GsrProfScope p(s, "row_hist");
+			gsr_launch_tilebin_row_hist(g, P, b, R, s);
 		}
-		if ((rc = gsr_stage_done(s, debug, "sort"))) return rc;
+		if ((rc = gsr_stage_done(s, debug, "row_hist"))) return rc;
+		{
+			GsrProfScope p(s, "row_scatter");
+			gsr_launch_tilebin_row_scatter(g, P, b, R, im.ranges, width, height, s);
+		}
+		if ((rc = gsr_stage_done(s, debug, "row_scatter"))) return rc;
+	} else {
+		if (R > 0) {
+			const int bit = (int)gsr_get_higher_msb((uint32_t)ntiles);  // key bits above the depth word, rasterizer_impl.cu:355
+			// emit into whichever buffer pair makes the ping-pong sort finish in (tile_keys, point_list)
+			const bool even = gsr_radix_num_passes(bit) % 2 == 0;
+			uint32_t *k0 = even ? b.tile_keys : b.tile_keys_alt, *v0 = even ? b.point_list : b.point_list_alt;
+			uint32_t *k1 = even ? b.tile_keys_alt : b.tile_keys, *v1 = even ? b.point_list_alt : b.point_list;
+			key_bytes = gsr_tile_key_bytes(ntiles, (size_t)R);  // 16-bit tile ids whenever they fit: a quarter less traffic in emission, sort, ranges
+			{
+				GsrProfScope p(s, "duplicate_keys");
+				gsr_launch_duplicate_keys(g, P, width, k0, key_bytes, v0, (uint32_t*)b.sort_table, gsr_radix_clear_words((size_t)R), s);
+			}
+			if ((rc = gsr_stage_done(s, debug, "duplicate_keys"))) return rc;
+			{
+				GsrProfScope p(s, "sort");
+				int in_first = 1;
+				gsr_radix_sort_u32(k0, v0, k1, v1, (size_t)R, bit, b.sort_table, &in_first, 0, key_bytes, s);  // chunk sums zeroed by duplicate_keys
+			}
+			if ((rc = gsr_stage_done(s, debug, "sort"))) return rc;
+		}
+		{
+			GsrProfScope p(s, "tile_ranges");
+			gsr_launch_tile_ranges(b.tile_keys, key_bytes, R, im.ranges, ntiles, b.tile_keys_alt, s);
+		}
+		if ((rc = gsr_stage_done(s, debug, "tile_ranges"))) return rc;
 	}
-	{
-		GsrProfScope p(s, "tile_ranges");
-		gsr_launch_tile_ranges(b.tile_keys, key_bytes, R, im.ranges, ntiles, b.tile_keys_alt, s);
-	}
-	if ((rc = gsr_stage_done(s, debug, "tile_ranges"))) return rc;
 	if (R > 0) {  // (measured at C3: the forward's own order is worth 33 us of blend time for ~12 us of this kernel and its launch)
 		GsrProfScope p(s, "tile_order");
-		gsr_launch_tile_order(im, ntiles, false, R, !(debug & GSR_DEBUG_NO_SPLIT), s);
+		gsr_launch_tile_order(im, ntiles, false, R, !(debug & GSR_DEBUG_NO_SPLIT), s, col_pairs);
 	}
 	if ((rc = gsr_stage_done(s, debug, "tile_order"))) return rc;
 	{

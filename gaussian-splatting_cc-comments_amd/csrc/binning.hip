@@ -277,7 +277,8 @@ extern "C" int gsr_debug_backward_key(uint32_t* key) { g_debug_backward_key = ke
 // first, at most max_split tiles; the entries [ntiles + 3 nsplit, ntiles + 3 max_split) are marked empty.
 __global__ void __launch_bounds__(1024) gsr_tile_order_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ tile_max_contrib,
                                                               uint32_t ntiles, uint32_t* __restrict__ order, int split_bin_max, uint32_t max_split,
-                                                              uint32_t* __restrict__ tile_max_contrib_out, uint32_t seg_budget, int allow_cut)
+                                                              uint32_t* __restrict__ tile_max_contrib_out, uint32_t seg_budget, int allow_cut,
+                                                              uint2* __restrict__ ranges_fix)
 {
 	__shared__ uint32_t bin[GSR_ORDER_BINS];
 	__shared__ uint32_t wsum[1024 / 64];
@@ -294,7 +295,14 @@ __global__ void __launch_bounds__(1024) gsr_tile_order_kernel(const uint2* __res
 		const uint32_t t = j * 1024 + threadIdx.x;
 		w0[j] = t < ntiles ? gsr_tile_work(ranges, tile_max_contrib, t) : 0u;
 		b0[j] = t < ntiles ? gsr_tile_work_bin(w0[j]) : 0xffffffffu;
+		// the column-pair binning (tilebin.hip) leaves a tile without instances as (p, p): the reference has (0, 0) there
+		if (ranges_fix && t < ntiles && w0[j] == 0u) ranges_fix[t] = make_uint2(0u, 0u);
 	}
+	if (ranges_fix)
+		for (uint32_t t = 1024 * GSR_ORDER_PER_THREAD + threadIdx.x; t < ntiles; t += 1024) {
+			const uint2 r = ranges_fix[t];
+			if (r.x == r.y) ranges_fix[t] = make_uint2(0u, 0u);
+		}
 	__syncthreads();
 	// Backward only (seg_budget > 0): a HEAVY tile -- one whose walk min(range, deepest n_contrib) is at least two checkpoint
 	// strides -- is handed out as one entry per DEPTH SEGMENT (entry = tile | (segment + 1) << 28): the forward left per-pixel
@@ -390,7 +398,7 @@ __global__ void __launch_bounds__(1024) gsr_tile_order_kernel(const uint2* __res
 uint32_t gsr_tile_order_max_segments(int ntiles) { return (uint32_t)(ntiles < 64 ? 0 : (ntiles / 2 < 4096 ? ntiles / 2 : 4096)); }
 uint32_t gsr_tile_order_max_split(int ntiles) { return (uint32_t)(ntiles < 64 ? 0 : (ntiles / 4 < 2048 ? ntiles / 4 : 2048)); }
 
-void gsr_launch_tile_order(GsrImage img, int ntiles, bool backward, int64_t num_rendered, bool split, hipStream_t s)
+void gsr_launch_tile_order(GsrImage img, int ntiles, bool backward, int64_t num_rendered, bool split, hipStream_t s, bool normalise_empty)
 {
 	const uint32_t* key = backward ? img.tile_max_contrib : (const uint32_t*)nullptr;
 	const uint2* ranges = img.ranges;
@@ -413,7 +421,7 @@ void gsr_launch_tile_order(GsrImage img, int ntiles, bool backward, int64_t num_
 	if (!ranges) allow_cut = 0;
 #endif
 	hipLaunchKernelGGL(gsr_tile_order_kernel, dim3(1), dim3(1024), 0, s, ranges, key, (uint32_t)ntiles, img.tile_order, split_bin_max, max_split,
-	                   img.tile_max_contrib, seg_budget, allow_cut);
+	                   img.tile_max_contrib, seg_budget, allow_cut, (normalise_empty && !backward) ? img.ranges : (uint2*)nullptr);
 }
 
 void gsr_launch_tile_ranges(const void* tile_keys, int key_bytes, int64_t R, uint2* ranges, int ntiles, uint32_t* valid, hipStream_t s)

@@ -39,6 +39,7 @@ struct GsrGeometry {
 
 	uint32_t* sorted_block_sums;  // per-workgroup tile counts in depth order (the key emission takes their prefix sums itself)
 	void* sort_table;             // radix histogram table for the P-sized depth sort
+	void* col_table;              // tilebin.hip, pass 1 (column pairs by tile column): chunk sums, block rows, digit totals
 };
 
 // Depth checkpoints of heavy tiles (lists of at least 2 * GSR_CKPT_STRIDE instances): every GSR_CKPT_STRIDE instances the forward
@@ -121,9 +122,20 @@ void gsr_launch_mark_visible(int P, const float* means3D, const float* viewmatri
 void gsr_launch_sorted_block_sums(GsrGeometry g, int P, int result_in_alt, hipStream_t s);
 void gsr_launch_duplicate_keys(GsrGeometry g, int P, int W, void* keys, int key_bytes, uint32_t* vals, uint32_t* clear, size_t clear_words, hipStream_t s);
 void gsr_launch_tile_ranges(const void* tile_keys, int key_bytes, int64_t R, uint2* ranges, int ntiles, uint32_t* valid, hipStream_t s);
-void gsr_launch_tile_order(GsrImage img, int ntiles, bool backward, int64_t num_rendered, bool split, hipStream_t s);
+void gsr_launch_tile_order(GsrImage img, int ntiles, bool backward, int64_t num_rendered, bool split, hipStream_t s, bool normalise_empty = false);
 uint32_t gsr_tile_order_max_split(int ntiles);      // forward: tiles that may be split into four band entries
 uint32_t gsr_tile_order_max_segments(int ntiles);   // backward: extra entries for the depth segments of heavy tiles
+
+// tilebin.hip: the sorted instance list by column pairs (images of at most 256 x 256 tiles)
+bool gsr_tilebin_applies(int W, int H);
+size_t gsr_tilebin_col_clear_words(size_t P);   // leading words of col_table that the preprocess kernel zeroes
+size_t gsr_tilebin_col_table_bytes(size_t P);
+size_t gsr_tilebin_row_clear_words(size_t R);
+size_t gsr_tilebin_row_table_bytes(size_t R);
+void gsr_launch_tilebin_col_hist(GsrGeometry g, int P, int result_in_alt, hipStream_t s);
+void gsr_launch_tilebin_col_scatter(GsrGeometry g, int P, GsrBinning b, int64_t R, hipStream_t s);
+void gsr_launch_tilebin_row_hist(GsrGeometry g, int P, GsrBinning b, int64_t R, hipStream_t s);
+void gsr_launch_tilebin_row_scatter(GsrGeometry g, int P, GsrBinning b, int64_t R, uint2* ranges, int W, int H, hipStream_t s);
 
 // sort.hip
 int gsr_radix_num_passes(int nbits_total);

@@ -42,7 +42,8 @@ __device__ __forceinline__ float gsr_sh_channel(int deg, const float* sh, int ch
 //
 // LEAF: the inputs are the optimiser's raw leaves (gsr_internal.h); activations happen here.
 template <bool LEAF>
-__global__ void __launch_bounds__(GSR_PREPROCESS_BLOCK) gsr_preprocess_kernel(GsrPreprocessArgs a, uint32_t* __restrict__ clear, size_t clear_words)
+__global__ void __launch_bounds__(GSR_PREPROCESS_BLOCK) gsr_preprocess_kernel(GsrPreprocessArgs a, uint32_t* __restrict__ clear, size_t clear_words,
+                                                                              uint32_t* __restrict__ clear2, size_t clear2_words)
 {
 	const int idx = blockIdx.x * GSR_PREPROCESS_BLOCK + threadIdx.x;
 	// The Gaussian's inputs, unconditionally (a culled Gaussian wastes 44 bytes): every load of the wave is in flight at
@@ -161,6 +162,9 @@ __global__ void __launch_bounds__(GSR_PREPROCESS_BLOCK) gsr_preprocess_kernel(Gs
 	// zero the chunk sums of the depth sort's passes (sort.hip): one word per thread of the first workgroups
 	for (size_t w = (size_t)blockIdx.x * GSR_PREPROCESS_BLOCK + threadIdx.x; w < clear_words; w += (size_t)gridDim.x * GSR_PREPROCESS_BLOCK)
 		clear[w] = 0u;
+	// ... and those of the column-pair binning's first pass (tilebin.hip), whose histogram runs behind the depth sort
+	for (size_t w = (size_t)blockIdx.x * GSR_PREPROCESS_BLOCK + threadIdx.x; w < clear2_words; w += (size_t)gridDim.x * GSR_PREPROCESS_BLOCK)
+		clear2[w] = 0u;
 }
 
 // View-dependent colour (forward.cu:21-81, called at :306-312): colour = clamp0(SH(dir) + 0.5) into the record, the
@@ -247,8 +251,10 @@ void gsr_launch_preprocess(const GsrPreprocessArgs& a, hipStream_t s)
 	const int nb = (a.P + GSR_PREPROCESS_BLOCK - 1) / GSR_PREPROCESS_BLOCK;
 	uint32_t* clear = (uint32_t*)a.g.sort_table;
 	const size_t clear_words = gsr_radix_clear_words((size_t)a.P);
-	if (a.leaf) hipLaunchKernelGGL(gsr_preprocess_kernel<true>, dim3(nb), dim3(GSR_PREPROCESS_BLOCK), 0, s, a, clear, clear_words);
-	else hipLaunchKernelGGL(gsr_preprocess_kernel<false>, dim3(nb), dim3(GSR_PREPROCESS_BLOCK), 0, s, a, clear, clear_words);
+	uint32_t* clear2 = (uint32_t*)a.g.col_table;
+	const size_t clear2_words = gsr_tilebin_col_clear_words((size_t)a.P);
+	if (a.leaf) hipLaunchKernelGGL(gsr_preprocess_kernel<true>, dim3(nb), dim3(GSR_PREPROCESS_BLOCK), 0, s, a, clear, clear_words, clear2, clear2_words);
+	else hipLaunchKernelGGL(gsr_preprocess_kernel<false>, dim3(nb), dim3(GSR_PREPROCESS_BLOCK), 0, s, a, clear, clear_words, clear2, clear2_words);
 }
 
 // the colour kernel exists only for SH colours

@@ -19,6 +19,7 @@
 // min / max taken from 64-way partial maxima left by the preprocess kernel; the depth sort then needs only the
 // passes that cover the bits of max - min (3 instead of 4 for any view whose depth range is below 2^24 float steps).
 #include "gsr_internal.h"
+#include "gsr_radix_walk.h"
 
 #define GSR_SORT_THREADS 256
 #define GSR_SORT_RADIX 256
@@ -39,12 +40,6 @@
 #define GSR_SORT_ITEMS_HUGE 32
 #ifndef GSR_SORT_HUGE_N
 #define GSR_SORT_HUGE_N (32u << 20)
-#endif
-#ifndef GSR_WALK_ROWS
-#define GSR_WALK_ROWS 8    // rows of the offset tables a wave keeps in flight (one uint4 per lane each)
-#endif
-#ifndef GSR_SORT_CHUNK
-#define GSR_SORT_CHUNK 64   // blocks per chunk, chunks per super-chunk of the three-level offset table
 #endif
 
 // min / range of the biased keys from the 64 + 64 partial maxima {max(~key)}, {max(key)} (GsrGeometry::status)
@@ -183,44 +178,7 @@ __global__ void __launch_bounds__(GSR_SORT_THREADS) gsr_radix_scatter_kernel(
 	{
 		uint32_t v = 0, before = 0;
 		if constexpr (ITEMS >= GSR_SORT_ITEMS_LARGE) {
-			const int my_chunk = blockIdx.x / GSR_SORT_CHUNK, my_super = my_chunk / GSR_SORT_CHUNK;
-			const bool three_level = nchunks > GSR_SORT_CHUNK;  // uniform
-			const int nS = three_level ? (nchunks + GSR_SORT_CHUNK - 1) / GSR_SORT_CHUNK : 0;
-			// two levels: every chunk (total, and the part in front); three levels: only the chunks of this super-chunk in front
-			const int c_first = three_level ? my_super * GSR_SORT_CHUNK : 0, c_end = three_level ? my_chunk : nchunks;
-			const int nC = c_end - c_first;
-			const int b0 = my_chunk * GSR_SORT_CHUNK, nB = (int)blockIdx.x - b0;  // blocks of this chunk in front of this one
-			const int Q = nS + nC + nB;
-			const uint32_t* super_sums = chunk_sums + (size_t)nchunks * GSR_SORT_RADIX;
-			uint4 v4 = make_uint4(0u, 0u, 0u, 0u), bf4 = v4;
-			for (int q0 = wave; q0 < Q; q0 += GSR_WALK_ROWS * (GSR_SORT_THREADS / 64)) {
-				uint4 t[GSR_WALK_ROWS];
-#pragma unroll
-				for (int j = 0; j < GSR_WALK_ROWS; j++) {
-					const int q = q0 + j * (GSR_SORT_THREADS / 64);
-					const uint32_t* row = q < nS ? super_sums + (size_t)q * GSR_SORT_RADIX
-					                    : q < nS + nC ? chunk_sums + (size_t)(c_first + q - nS) * GSR_SORT_RADIX
-					                                  : table + (size_t)(b0 + q - nS - nC) * GSR_SORT_RADIX;
-					t[j] = q < Q ? reinterpret_cast<const uint4*>(row)[lane] : make_uint4(0u, 0u, 0u, 0u);
-				}
-#pragma unroll
-				for (int j = 0; j < GSR_WALK_ROWS; j++) {
-					const int q = q0 + j * (GSR_SORT_THREADS / 64);
-					const bool to_total = three_level ? q < nS : (q >= nS && q < nS + nC);
-					const bool to_before = q < nS ? q < my_super : (q < nS + nC ? c_first + q - nS < my_chunk : true);
-					if (to_total) { v4.x += t[j].x; v4.y += t[j].y; v4.z += t[j].z; v4.w += t[j].w; }
-					if (to_before) { bf4.x += t[j].x; bf4.y += t[j].y; bf4.z += t[j].z; bf4.w += t[j].w; }
-				}
-			}
-			uint4* part = reinterpret_cast<uint4*>(sstage);  // [total | before][wave][lane] uint4 = [total | before][wave][digit] words
-			part[wave * 64 + lane] = v4;
-			part[(GSR_SORT_THREADS / 64 + wave) * 64 + lane] = bf4;
-			__syncthreads();
-#pragma unroll
-			for (int w = 0; w < GSR_SORT_THREADS / 64; w++) {
-				v += sstage[w * GSR_SORT_RADIX + threadIdx.x];
-				before += sstage[(GSR_SORT_THREADS / 64 + w) * GSR_SORT_RADIX + threadIdx.x];
-			}
+			gsr_radix_walk_256(table, chunk_sums, nchunks, nchunks, (int)blockIdx.x, sstage, v, before);  // (gsr_radix_walk.h; the staging area is not in use yet)
 		} else {
 			// Gaussian-sized sorts (1024-element blocks): a block lives too briefly for the extra barrier of the
 			// cooperative walk to pay (measured: 71 -> 81 us for the three depth passes at P = 1M); thread d walks word d of the

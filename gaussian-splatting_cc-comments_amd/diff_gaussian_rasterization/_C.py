@@ -28,7 +28,7 @@ _sz = ctypes.c_size_t
 
 class GeometryLayout(ctypes.Structure):
     _fields_ = [(n, _sz) for n in ("splat", "depth_keys", "depth_keys_alt", "perm", "perm_alt", "tiles_touched", "rect",
-                                   "slot_base", "clamped", "sh_ddir", "status", "scan_temp", "sort_table", "total")]
+                                   "slot_base", "clamped", "sh_ddir", "status", "scan_temp", "sort_table", "col_table", "total")]
 
 
 class ImageLayout(ctypes.Structure):
@@ -37,7 +37,7 @@ class ImageLayout(ctypes.Structure):
 
 class BinningLayout(ctypes.Structure):
     _fields_ = [(n, _sz) for n in ("point_list", "point_list_alt", "tile_keys", "tile_keys_alt", "sort_table",
-                                   "checkpoints", "total", "tile_key_bytes")]
+                                   "checkpoints", "total", "tile_key_bytes", "column_pairs")]
 
 
 class KernelTime(ctypes.Structure):
@@ -59,7 +59,7 @@ class BackwardArgs(ctypes.Structure):
 
 # bits of the C ABI's `debug` mask (include/gsr.h GSR_DEBUG_*).  The reference's bool `debug` is DEBUG_SYNC; tests pass the
 # diagnostic bits as an int in the same argument, per call -- nothing is read from the environment.
-DEBUG_SYNC, DEBUG_NO_CULL, DEBUG_SERIAL, DEBUG_NO_SPLIT = 1, 2, 4, 8
+DEBUG_SYNC, DEBUG_NO_CULL, DEBUG_SERIAL, DEBUG_NO_SPLIT, DEBUG_TILE_SORT = 1, 2, 4, 8, 16
 
 
 def _dbg(debug):

@@ -45,6 +45,9 @@ typedef enum {
 #define GSR_DEBUG_NO_CULL 2  /* blend kernels evaluate every (instance, pixel band) pair of a tile's list, like the reference,
                                 instead of skipping the pairs proven to contribute nothing: bisects a suspected culling error */
 #define GSR_DEBUG_SERIAL  4  /* gsr_forward_preprocess*: the SH colour kernel runs in line on `stream`, not on the helper stream */
+#define GSR_DEBUG_TILE_SORT 16 /* gsr_forward_preprocess* AND gsr_forward_render (pass it to both or to neither): instances are emitted
+                                 with their tile ids and radix-sorted (the path of images beyond 256 x 256 tiles) instead of being
+                                 binned by column pairs; same point_list, same ranges */
 #define GSR_DEBUG_NO_SPLIT 8 /* gsr_forward_render: heavy tiles (instance lists >= 1024 and >= 2x the mean) are blended by one wave like
                                 every other tile, not by four waves of one 16x4-pixel band each (same results either way) */
 
@@ -86,6 +89,7 @@ typedef struct {
 	                          counts; 68..131 / 132..195: partial maxima of ~depth key / depth key of the visible Gaussians) */
 	size_t scan_temp;      /* per-workgroup tile counts in depth order */
 	size_t sort_table;     /* radix histogram table of the depth sort */
+	size_t col_table;      /* column-pair binning, pass 1 (by tile column): chunk sums, per-workgroup digit rows, 256 digit totals */
 	size_t total;
 } gsr_geometry_layout;
 
@@ -109,6 +113,9 @@ typedef struct {
 	size_t checkpoints;    /* [R / 1024 + 2][256] float4: per-pixel (T, C) of heavy tiles every 1024 instances of their walk */
 	size_t total;
 	size_t tile_key_bytes; /* 2 (uint16_t: every tile id of the image is below 65 536) or 4 (uint32_t); both arrays are sized for 4 */
+	size_t column_pairs;   /* 1: images of at most 256 x 256 tiles are binned by column pairs (no per-instance tile keys exist: the tile
+	                          of sorted instance i follows from `ranges`; tile_keys then holds the sorted column pairs, u16 y0 | h - 1 << 8,
+	                          point_list_alt their Gaussian ids) unless GSR_DEBUG_TILE_SORT is passed; 0: always the tile sort */
 } gsr_binning_layout;
 
 int gsr_geometry_layout_of(int P, gsr_geometry_layout* out);

@@ -207,8 +207,18 @@ def _properties(name, check_linearity=True):
     tiles_touched = u32(cap["geom"], gl.tiles_touched, P).to(torch.int64)
     assert int(tiles_touched.sum()) == R
     assert torch.equal(tiles_touched > 0, radii > 0)
-    kb = int(bl.tile_key_bytes)
-    tile_keys = cap["binning"][bl.tile_keys:bl.tile_keys + kb * R].view(torch.int16 if kb == 2 else torch.int32).to(torch.int64) & (0xFFFF if kb == 2 else 0xFFFFFFFF)
+    ranges = u32(cap["img"], il.ranges, 2 * T).view(T, 2).to(torch.int64)
+    lens = ranges[:, 1] - ranges[:, 0]
+    assert int(lens.sum()) == R and bool((lens >= 0).all())
+    if int(bl.column_pairs):
+        # column-pair binning: no per-instance keys are stored; the tile of instance i is the tile whose range holds i.  The
+        # ranges must partition [0, R) in tile order ...
+        ne0 = lens > 0
+        assert torch.equal(ranges[ne0, 0], torch.cumsum(lens[ne0], 0) - lens[ne0])
+        tile_keys = torch.repeat_interleave(torch.arange(T, device=dev), lens)
+    else:
+        kb = int(bl.tile_key_bytes)
+        tile_keys = cap["binning"][bl.tile_keys:bl.tile_keys + kb * R].view(torch.int16 if kb == 2 else torch.int32).to(torch.int64) & (0xFFFF if kb == 2 else 0xFFFFFFFF)
     plist = u32(cap["binning"], bl.point_list, R).to(torch.int64)
     assert bool((tile_keys[1:] >= tile_keys[:-1]).all()), "instances sorted by tile"
     assert int(tile_keys.max()) < T
@@ -225,9 +235,23 @@ def _properties(name, check_linearity=True):
     assert bool((d[1:][same_tile] >= d[:-1][same_tile]).all()), "depth-sorted inside every tile"
     tie = same_tile & (d[1:] == d[:-1])
     assert bool((plist[1:][tie] > plist[:-1][tie]).all()), "stable: equal keys keep ascending Gaussian index"
-    ranges = u32(cap["img"], il.ranges, 2 * T).view(T, 2).to(torch.int64)
-    lens = ranges[:, 1] - ranges[:, 0]
-    assert int(lens.sum()) == R and bool((lens >= 0).all())
+    # ... and every instance must sit in a tile of its Gaussian's rectangle, every rectangle tile exactly once: per tile, the
+    # number of instances = the number of rectangles that cover it (a 2-D difference array over the tile grid)
+    gxt = (W + 15) // 16
+    rect = u32(cap["geom"], gl.rect, 2 * P).view(P, 2).to(torch.int64)
+    rx0, ry0, rw, rh = rect[:, 0] & 0xFFFF, rect[:, 0] >> 16, rect[:, 1] & 0xFFFF, (rect[:, 1] >> 16) & 0xFFFF
+    tx, ty = tile_keys % gxt, tile_keys // gxt
+    gi = plist
+    assert bool(((tx >= rx0[gi]) & (tx < rx0[gi] + rw[gi]) & (ty >= ry0[gi]) & (ty < ry0[gi] + rh[gi])).all()), "instance outside its Gaussian's rectangle"
+    gyt = (H + 15) // 16
+    diff = torch.zeros((gyt + 1) * (gxt + 1), dtype=torch.int64, device=dev)
+    vis = (rw * rh) > 0
+    for sx, sy, sign in ((rx0, ry0, 1), (rx0 + rw, ry0, -1), (rx0, ry0 + rh, -1), (rx0 + rw, ry0 + rh, 1)):
+        diff.index_add_(0, (sy[vis] * (gxt + 1) + sx[vis]), torch.full((int(vis.sum()),), sign, dtype=torch.int64, device=dev))
+    cover = diff.view(gyt + 1, gxt + 1).cumsum(0).cumsum(1)[:gyt, :gxt].reshape(-1)
+    assert torch.equal(cover, lens), "per-tile instance counts differ from the rectangles' coverage"
+    key2 = tile_keys * P + plist
+    assert int(torch.unique(key2).numel()) == R, "a (tile, Gaussian) pair appears twice"
     counts = torch.bincount(tile_keys, minlength=T)
     assert torch.equal(counts, lens)
     ne = lens > 0

@@ -121,3 +121,59 @@ def test_random_heavy_tile_scenes_match_oracle_split_or_not(seed):
     T = ((W + 15) // 16) * ((H + 15) // 16)
     lens = (h["ranges"][:, 1].astype(np.int64) - h["ranges"][:, 0])
     print(f"seed {seed}: {W}x{H} ({T} tiles) D{D} P{P} R={o['num_rendered']} longest list {int(lens.max())} mean {int(lens.mean())}")
+
+
+def _binning_pair(scene, cam, D, dpix, label):
+    """One scene through both binning paths -- column pairs (csrc/tilebin.hip, the default up to 256 x 256 tiles) and instance
+    emission + tile sort (GSR_DEBUG_TILE_SORT, the path of larger images): both against the oracle, and bit-identical to each
+    other in every output and in the sorted instance list and the ranges."""
+    from diff_gaussian_rasterization import _C
+    o = util.oracle_forward(scene, cam, D)
+    if dpix is None:
+        dpix = util.fragile_free_dpix(o, cam, seed=5)
+    a = util.hip_forward_backward(scene, cam, D, dpix)
+    b = util.hip_forward_backward(scene, cam, D, dpix, debug=_C.DEBUG_TILE_SORT)
+    check_forward(a, o, cam)
+    check_forward(b, o, cam)
+    for k in ("color", "radii", "final_T", "n_contrib", "ranges", "slot_base"):
+        assert np.array_equal(a[k], b[k]), (label, k)
+    if o["num_rendered"] > 0:
+        for k in ("point_list", "keys"):
+            assert np.array_equal(a[k], b[k]), (label, k)
+        for k in a["grads"]:
+            assert np.array_equal(a["grads"][k], b["grads"][k]), (label, k)
+    return o
+
+
+@pytest.mark.parametrize("seed", [0, 3, 5, 8])
+def test_column_pair_binning_and_tile_sort_agree_bit_for_bit(seed):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    r = np.random.default_rng(4000 + seed)
+    W, H = int(r.integers(40, 700)) | 1, int(r.integers(30, 400)) | 1
+    D = int(r.integers(0, 4))
+    P = int(r.integers(1500, 30000))
+    scene = gsr_scene.make_scene(P, float(r.uniform(-4.5, -2.0)), sh_degree=D, seed=seed + 70)
+    inside = seed % 2 == 1   # cameras inside the cloud: splats with rectangles of hundreds of tiles, Gaussians culled
+    eye = r.normal(size=3)
+    eye = eye / np.linalg.norm(eye) * (float(r.uniform(0.2, 1.2)) if inside else float(r.uniform(2.5, 5.0)))
+    R, T = _look_at(eye, r.uniform(-0.4, 0.4, 3))
+    cam = gsr_scene.make_camera(W, H, fovx=float(r.uniform(0.5, 1.7)), R=R, T=T)
+    o = _binning_pair(scene, cam, D, None, f"seed {seed}")
+    print(f"seed {seed}: {W}x{H} D{D} P{P} inside={inside} R={o['num_rendered']} max radius {int(o['radii'].max())}")
+
+
+@pytest.mark.parametrize("W,H", [(4096, 20), (4097, 20), (20, 4096), (20, 4100), (4090, 37), (1, 1), (16, 16)])
+def test_binning_at_the_256_tile_limit_of_the_column_pairs(W, H):
+    """Exactly 256 tile columns / rows (the widest digit of the column-pair passes), one tile more (the image takes the tile
+    sort by itself), and single-tile images."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from diff_gaussian_rasterization import _C
+    P, D = 3000, 1
+    scene = gsr_scene.make_scene(P, -2.5, sh_degree=D, seed=W + H)
+    # spread the Gaussians over the whole strip: a wide field of view along the long side
+    cam = gsr_scene.make_camera(W, H, fovx=2.6 if W > 4 * H else (0.02 if H > 4 * W else 1.0))
+    bl = _C.binning_layout(P, 1000, W, H)
+    assert int(bl.column_pairs) == (1 if (W + 15) // 16 <= 256 and (H + 15) // 16 <= 256 else 0)
+    _binning_pair(scene, cam, D, None, f"{W}x{H}")

@@ -50,6 +50,24 @@ def test_host_only_entry_points():
     assert rc == -1 and b"bad" in L.gsr_last_error()
 
 
+def test_layouts_of_the_column_pair_binning():
+    """Host-only: which images are binned by column pairs (at most 256 x 256 tiles), and the room the two passes need inside
+    the blobs -- pass 1: per-1024-Gaussian digit rows + 16 bytes per Gaussian in the geometry blob; pass 2: one digit row per
+    1024 column pairs (+ one per tile column) in the binning blob's table area; the sorted pairs (8 bytes, at most R of them)
+    in point_list_alt + tile_keys."""
+    from diff_gaussian_rasterization import _C
+    for W, H, want in ((1980, 1080, 1), (3840, 2160, 1), (4096, 4096, 1), (4097, 16, 0), (16, 4097, 0), (1, 1, 1)):
+        assert int(_C.binning_layout(10, 100, W, H).column_pairs) == want, (W, H)
+    for P in (1, 1000, 1_000_000):
+        gl = _C.geometry_layout(P)
+        blocks = (P + 1023) // 1024
+        assert gl.total - gl.col_table >= 4 * 256 * (blocks + 1) + 16 * P and gl.col_table >= gl.sort_table
+    for R in (1, 5000, 9_161_997):
+        bl = _C.binning_layout(1000, R, 1980, 1080)
+        assert bl.checkpoints - bl.sort_table >= 4 * 256 * (R // 1024 + 256)
+        assert bl.tile_keys_alt - bl.point_list_alt >= 8 * R and bl.total > bl.checkpoints
+
+
 def test_python_surface_matches_reference_shape():
     import diff_gaussian_rasterization as dgr
     # reference diff_gaussian_rasterization/__init__.py:168-180

@@ -74,7 +74,8 @@ def hip_forward_backward(scene, cam, D, dpix=None, dev="cuda:0", colors_precomp=
     finally:
         _C.rasterize_gaussians = orig
     out = dict(color=color.detach().cpu().numpy(), radii=radii.cpu().numpy(), num_rendered=captured["R"])
-    out.update(unpack_state(captured, means.shape[0], cam.image_width, cam.image_height))
+    tile_sort = isinstance(debug, int) and not isinstance(debug, bool) and bool(debug & _C.DEBUG_TILE_SORT)
+    out.update(unpack_state(captured, means.shape[0], cam.image_width, cam.image_height, tile_sort=tile_sort))
     if dpix is not None:
         raw = {}
         orig_b = _C.rasterize_gaussians_backward
@@ -108,7 +109,7 @@ def hip_forward_backward(scene, cam, D, dpix=None, dev="cuda:0", colors_precomp=
     return out
 
 
-def unpack_state(cap, P, W, H):
+def unpack_state(cap, P, W, H, tile_sort=False):
     from diff_gaussian_rasterization import _C
     R = cap["R"]
     o = {}
@@ -143,8 +144,18 @@ def unpack_state(cap, P, W, H):
     if R > 0:
         bl = _C.binning_layout(P, R, W, H)
         o["point_list"] = binning[bl.point_list:bl.point_list + 4 * R].view(np.uint32)
-        kb = int(bl.tile_key_bytes)   # 2: uint16 tile ids (every id of the image < 65 536), 4: uint32
-        o["tile_keys"] = binning[bl.tile_keys:bl.tile_keys + kb * R].view(np.uint16 if kb == 2 else np.uint32).astype(np.uint32)
+        if int(bl.column_pairs) and not tile_sort:
+            # column-pair binning (csrc/tilebin.hip): no per-instance tile key is ever stored; the tile of sorted instance i is
+            # the tile whose range holds i.  check_forward compares `ranges` and `point_list` with the oracle's directly; the
+            # keys below then restate that (and fail loudly if the ranges do not partition [0, R))
+            lens = (o["ranges"][:, 1] - o["ranges"][:, 0]).astype(np.int64)
+            ne = lens > 0
+            starts = o["ranges"][ne, 0].astype(np.int64)
+            assert int(lens.sum()) == R and np.array_equal(starts, np.concatenate([[0], np.cumsum(lens[ne])[:-1]])), "ranges do not partition [0, R) in tile order"
+            o["tile_keys"] = np.repeat(np.arange(T, dtype=np.uint32), lens)
+        else:
+            kb = int(bl.tile_key_bytes)   # 2: uint16 tile ids (every id of the image < 65 536), 4: uint32
+            o["tile_keys"] = binning[bl.tile_keys:bl.tile_keys + kb * R].view(np.uint16 if kb == 2 else np.uint32).astype(np.uint32)
         # the reference's 64-bit key of every sorted instance: tile id << 32 | depth bits
         o["keys"] = (o["tile_keys"].astype(np.uint64) << np.uint64(32)) | depth_bits[o["point_list"]].astype(np.uint64)
     return o
