@@ -31,7 +31,7 @@ import gsr_scene  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, corrected as
 # MI355X_MICROARCH.md "HBM" prescribes) of this same command, summarised by tools/pmc_summary.py
-PMC_SUMMARY = next((f for f in (os.path.join(ROOT, "profiles", n) for n in ("r3_pmc_summary.json", "r2_pmc_summary.json", "r1_pmc_summary.json"))
+PMC_SUMMARY = next((f for f in (os.path.join(ROOT, "profiles", n) for n in ("r3b_pmc_summary.json", "r3_pmc_summary.json", "r2_pmc_summary.json", "r1_pmc_summary.json"))
                     if os.path.exists(f)), os.path.join(ROOT, "profiles", "r3_pmc_summary.json"))
 KERNEL_SYMBOL = {"render_backward": "gsr_render_backward_wave_kernel", "render_forward": "gsr_render_forward_wave_kernel",
                  "gaussian_backward": "gsr_gaussian_backward_kernel", "preprocess": "gsr_preprocess_kernel",

@@ -153,7 +153,12 @@ __global__ void __launch_bounds__(64 * GSR_WAVES_PER_WG) __attribute__((amdgpu_w
 	uint32_t id_next = (64 + lane < nw) ? plist[top - 1 - (64 + lane)] : 0u;
 	const int out_index = lane >> 3;                  // 8-lane group c ends up holding the wave total of v[c]
 	float* const red_w = s_red[wave] + lane * 9;                       // this lane's row
-	const float* const red_r = s_red[wave] + (lane & 7) * 9 + (lane >> 3);   // column lane / 8, rows (lane % 8) + 8 k
+	// column lane / 8, rows (lane % 8) + 8 k.  (Two of the eight 8-lane groups share seven banks in each of these reads: 2 conflict
+	// cycles per read, SQ_LDS_BANK_CONFLICT = 25 M per launch at C3.  Rows 8 (lane % 8) + k are conflict-free and were measured:
+	// 0.4665 -> 0.464 ms, and the other summation order put one needle-splat fuzz case 2 % over its end-to-end bar on
+	// dL/drotations (blend sums unchanged at 1e-6): not kept.)
+	const float* const red_r = s_red[wave] + (lane & 7) * 9 + (lane >> 3);
+	constexpr int red_step = 72;
 	const float out_scale = (out_index >= 2 && out_index <= 4) ? -0.5f : 1.0f;
 	const float k01 = out_index == 0 ? -ddelx_dx : -ddely_dy;   // backward.cu:574-575: dL/dmean2D is scaled by 0.5 W / 0.5 H
 
@@ -279,7 +284,7 @@ __global__ void __launch_bounds__(64 * GSR_WAVES_PER_WG) __attribute__((amdgpu_w
 				for (int i = 0; i < 8; i++) red_w[i] = v[i];
 				float col[8];
 #pragma unroll
-				for (int k = 0; k < 8; k++) col[k] = red_r[72 * k];
+				for (int k = 0; k < 8; k++) col[k] = red_r[red_step * k];
 				// the ninth value's DPP chain runs while the LDS round trip is under way
 				__builtin_amdgcn_sched_barrier(0);
 				const float t9 = gsr_wave_sum_to_lane63(v[8]);  // lane 63 holds the total of v[8]
