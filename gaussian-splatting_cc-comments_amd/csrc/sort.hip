@@ -76,60 +76,70 @@ __device__ __forceinline__ size_t gsr_sort_index(int block, int wave, int it, in
 	return (size_t)block * (GSR_SORT_THREADS * ITEMS) + (size_t)wave * (64 * ITEMS) + (size_t)it * 64 + lane;
 }
 
+// blocks_per_wg (a power of two <= GSR_SORT_CHUNK): a workgroup counts that many CONSECUTIVE blocks -- all in one chunk -- and adds
+// to the chunk (super-chunk) sums once, from registers: every address of those rows otherwise takes 64 (4 096) adders, which
+// serialise in the L2 (C5, the depth sort of 6 M Gaussians in 5 860 blocks: three-level tables).  1 for small sorts, whose
+// histogram kernels are a few microseconds of latency.
 template <int ITEMS, typename KeyT>
 __global__ void __launch_bounds__(GSR_SORT_THREADS) gsr_radix_hist_kernel(const KeyT* __restrict__ keys, size_t n,
                                                                           int shift, uint32_t mask,
                                                                           uint32_t* __restrict__ table, int nblocks,
                                                                           uint32_t* __restrict__ chunk_sums, int nchunks,
-                                                                          const uint32_t* __restrict__ bias)
+                                                                          const uint32_t* __restrict__ bias, int blocks_per_wg)
 {
 	__shared__ uint32_t hist[GSR_SORT_RADIX];
 	__shared__ uint32_t s_bias[2];
-	hist[threadIdx.x] = 0;
 	const GsrKeyBias kb = gsr_sort_bias(bias, s_bias);
 	const bool biased = bias != nullptr;
-	__syncthreads();
 	// the histogram does not care which thread counts which element of the block's tile: 16-byte loads (4 keys of 32 bits or
 	// 8 keys of 16 bits each)
 	constexpr int TILE = GSR_SORT_THREADS * ITEMS;
 	constexpr int KPV = 16 / (int)sizeof(KeyT), NV = ITEMS / KPV;
 	static_assert(NV >= 1 && NV * KPV == ITEMS, "a thread's keys must fill whole 16-byte loads");
-	const size_t first = (size_t)blockIdx.x * TILE;
-	if (first + TILE <= n) {
-		const uint4* src = reinterpret_cast<const uint4*>(keys + first);  // tile starts are multiples of 1024 elements
-		uint4 v[NV];
+	uint32_t acc = 0u;
+	const int block0 = (int)blockIdx.x * blocks_per_wg;
+	for (int block = block0; block < block0 + blocks_per_wg && block < nblocks; block++) {
+		__syncthreads();  // (the previous block's counts have been read)
+		hist[threadIdx.x] = 0;
+		__syncthreads();
+		const size_t first = (size_t)block * TILE;
+		if (first + TILE <= n) {
+			const uint4* src = reinterpret_cast<const uint4*>(keys + first);  // tile starts are multiples of 1024 elements
+			uint4 v[NV];
 #pragma unroll
-		for (int it = 0; it < NV; it++) v[it] = src[it * GSR_SORT_THREADS + threadIdx.x];
+			for (int it = 0; it < NV; it++) v[it] = src[it * GSR_SORT_THREADS + threadIdx.x];
 #pragma unroll
-		for (int it = 0; it < NV; it++) {
-			const uint32_t w[4] = {v[it].x, v[it].y, v[it].z, v[it].w};
+			for (int it = 0; it < NV; it++) {
+				const uint32_t w[4] = {v[it].x, v[it].y, v[it].z, v[it].w};
 #pragma unroll
-			for (int c = 0; c < 4; c++) {
-				if constexpr (sizeof(KeyT) == 4) {
-					atomicAdd(&hist[(gsr_sort_key(w[c], kb, biased) >> shift) & mask], 1u);
-				} else {
-					atomicAdd(&hist[((w[c] & 0xffffu) >> shift) & mask], 1u);
-					atomicAdd(&hist[((w[c] >> 16) >> shift) & mask], 1u);
+				for (int c = 0; c < 4; c++) {
+					if constexpr (sizeof(KeyT) == 4) {
+						atomicAdd(&hist[(gsr_sort_key(w[c], kb, biased) >> shift) & mask], 1u);
+					} else {
+						atomicAdd(&hist[((w[c] & 0xffffu) >> shift) & mask], 1u);
+						atomicAdd(&hist[((w[c] >> 16) >> shift) & mask], 1u);
+					}
 				}
 			}
-		}
-	} else {
-		const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+		} else {
+			const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll
-		for (int it = 0; it < ITEMS; it++) {
-			const size_t i = gsr_sort_index<ITEMS>(blockIdx.x, wave, it, lane);
-			if (i < n) atomicAdd(&hist[(gsr_sort_key((uint32_t)keys[i], kb, biased) >> shift) & mask], 1u);
+			for (int it = 0; it < ITEMS; it++) {
+				const size_t i = gsr_sort_index<ITEMS>(block, wave, it, lane);
+				if (i < n) atomicAdd(&hist[(gsr_sort_key((uint32_t)keys[i], kb, biased) >> shift) & mask], 1u);
+			}
 		}
+		__syncthreads();
+		const uint32_t c = hist[threadIdx.x];
+		table[(size_t)block * GSR_SORT_RADIX + threadIdx.x] = c;  // [block][digit]: a block's row is one coalesced kilobyte
+		acc += c;
 	}
-	__syncthreads();
-	const uint32_t c = hist[threadIdx.x];
-	table[(size_t)blockIdx.x * GSR_SORT_RADIX + threadIdx.x] = c;  // [block][digit]: a block's row is one coalesced kilobyte
-	if (c) {  // [chunk][digit] and, behind them, [super-chunk][digit]: zeroed beforehand
-		atomicAdd(&chunk_sums[(size_t)(blockIdx.x / GSR_SORT_CHUNK) * GSR_SORT_RADIX + threadIdx.x], c);
+	if (acc) {  // [chunk][digit] and, behind them, [super-chunk][digit]: zeroed beforehand
+		atomicAdd(&chunk_sums[(size_t)(block0 / GSR_SORT_CHUNK) * GSR_SORT_RADIX + threadIdx.x], acc);
 		// the third level only where the second alone would be long (> 64 chunks = 262 144 blocks' worth of elements / 64):
-		// its rows take 4 096 adders each (measured: +35 us per pass at 2 236 blocks when every block added to ONE row)
+		// its rows take 4 096 / blocks_per_wg adders each (measured: +35 us per pass at 2 236 blocks when every block added to ONE row)
 		if (nchunks > GSR_SORT_CHUNK)
-			atomicAdd(&chunk_sums[(size_t)(nchunks + blockIdx.x / (GSR_SORT_CHUNK * GSR_SORT_CHUNK)) * GSR_SORT_RADIX + threadIdx.x], c);
+			atomicAdd(&chunk_sums[(size_t)(nchunks + block0 / (GSR_SORT_CHUNK * GSR_SORT_CHUNK)) * GSR_SORT_RADIX + threadIdx.x], acc);
 	}
 }
 
@@ -350,8 +360,11 @@ static void gsr_radix_pass(const KeyT* ki, const uint32_t* vi, KeyT* ko, uint32_
 {
 	const int nblocks = (int)((n + (size_t)GSR_SORT_THREADS * ITEMS - 1) / ((size_t)GSR_SORT_THREADS * ITEMS));
 	const uint32_t mask = (1u << bits) - 1u;
-	hipLaunchKernelGGL((gsr_radix_hist_kernel<ITEMS, KeyT>), dim3(nblocks), dim3(GSR_SORT_THREADS), 0, s, ki, n, shift, mask, table, nblocks,
-	                   chunk_sums, nchunks, bias);
+	// consecutive blocks per histogram workgroup: 1 up to 2 048 blocks, then as many as keep >= 1 024 workgroups (at most a chunk)
+	int per = 1;
+	while (per < GSR_SORT_CHUNK && nblocks / (2 * per) >= 1024) per *= 2;
+	hipLaunchKernelGGL((gsr_radix_hist_kernel<ITEMS, KeyT>), dim3((nblocks + per - 1) / per), dim3(GSR_SORT_THREADS), 0, s, ki, n, shift, mask, table,
+	                   nblocks, chunk_sums, nchunks, bias, per);
 	hipLaunchKernelGGL((gsr_radix_scatter_kernel<ITEMS, KeyT>), dim3(nblocks), dim3(GSR_SORT_THREADS), 0, s, ki, vi, ko, vo, n, shift, bits,
 	                   table, nblocks, chunk_sums, nchunks, bias);
 }

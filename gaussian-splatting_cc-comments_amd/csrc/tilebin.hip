@@ -82,22 +82,6 @@ __device__ __forceinline__ uint32_t tb_wave_incl_scan(uint32_t v)
 	return v;
 }
 
-// Workgroup histogram of segments from a difference array: diff (TB_RADIX + 1 ints, zeroed, then +1 at d0 and -1 at d0 + len of
-// every segment) -> thread d gets the number of elements with digit d.  Writes the block's table row and adds it to the chunk
-// (and, three levels, super-chunk) sums.
-__device__ __forceinline__ void tb_publish_histogram(const int32_t* diff, uint32_t* wsum, int block, uint32_t* __restrict__ table,
-                                                     uint32_t* __restrict__ chunk_sums, int nchunks, int chunk_rows)
-{
-	const uint32_t c = (uint32_t)diff[threadIdx.x];
-	const uint32_t cnt = gsr_excl_scan_256(c, wsum) + c;   // (wrapping arithmetic: the prefix sums themselves are >= 0)
-	table[(size_t)block * TB_RADIX + threadIdx.x] = cnt;
-	if (cnt) {
-		atomicAdd(&chunk_sums[(size_t)(block / GSR_SORT_CHUNK) * TB_RADIX + threadIdx.x], cnt);
-		if (nchunks > GSR_SORT_CHUNK)
-			atomicAdd(&chunk_sums[(size_t)(chunk_rows + block / (GSR_SORT_CHUNK * GSR_SORT_CHUNK)) * TB_RADIX + threadIdx.x], cnt);
-	}
-}
-
 // Per-wave digit counts of the wave's 4 x 64 segments (difference array in LDS, prefix sum over the digits by the wave itself):
 // wcount[d] = elements of digit d the wave will generate.  wdiff: TB_RADIX + 4 ints of this wave.
 __device__ __forceinline__ void tb_wave_counts(const uint32_t (&d0)[TB_GROUPS], const uint32_t (&len)[TB_GROUPS], int32_t* wdiff, uint32_t* wcount)
@@ -223,44 +207,59 @@ __device__ __forceinline__ void tb_expand_group(uint32_t d0, uint32_t len, uint3
 // (the scatter kernel takes the prefix sums for the gradient-slot numbering), and records where the depth sort left its
 // result.  Runs in forward stage 1, behind the depth sort, while the host waits for the count.
 __global__ void __launch_bounds__(TB_THREADS) gsr_tb_col_hist_kernel(const uint32_t* __restrict__ perm, const uint2* __restrict__ rect, int P,
-                                                                     uint32_t* __restrict__ block_sums, uint32_t* __restrict__ table,
+                                                                     uint32_t* __restrict__ block_sums, uint32_t* __restrict__ table, int nblocks,
                                                                      uint32_t* __restrict__ chunk_sums, int nchunks, uint4* __restrict__ seg,
-                                                                     uint32_t* __restrict__ status, uint32_t result_in_alt)
+                                                                     uint32_t* __restrict__ status, uint32_t result_in_alt, int blocks_per_wg)
 {
 	__shared__ int32_t diff[TB_RADIX + 4];
 	__shared__ uint32_t wsum[TB_WAVES];
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-	diff[threadIdx.x] = 0;
-	if (threadIdx.x < 4) diff[TB_RADIX + threadIdx.x] = 0;
 	if (blockIdx.x == 0 && threadIdx.x == 0) status[2] = result_in_alt;
-	uint32_t id[TB_GROUPS];
-	uint2 rc[TB_GROUPS];
+	// blocks_per_wg consecutive blocks (a power of two <= 64: one chunk) per workgroup, their counts added to the chunk and
+	// super-chunk sums once, from registers (sort.hip gsr_radix_hist_kernel: the adders per address of those rows)
+	uint32_t acc = 0u;
+	const int block0 = (int)blockIdx.x * blocks_per_wg;
+	for (int block = block0; block < block0 + blocks_per_wg && block < nblocks; block++) {
+		diff[threadIdx.x] = 0;
+		if (threadIdx.x < 4) diff[TB_RADIX + threadIdx.x] = 0;
+		uint32_t id[TB_GROUPS];
+		uint2 rc[TB_GROUPS];
 #pragma unroll
-	for (int q = 0; q < TB_GROUPS; q++) {
-		const int i = blockIdx.x * TB_BLOCK + wave * (64 * TB_GROUPS) + q * 64 + lane;
-		id[q] = i < P ? perm[i] : 0xFFFFFFFFu;
-	}
-#pragma unroll
-	for (int q = 0; q < TB_GROUPS; q++) rc[q] = id[q] != 0xFFFFFFFFu ? rect[id[q]] : make_uint2(0u, 0u);
-	__syncthreads();
-	uint32_t tiles = 0;
-#pragma unroll
-	for (int q = 0; q < TB_GROUPS; q++) {
-		const int i = blockIdx.x * TB_BLOCK + wave * (64 * TB_GROUPS) + q * 64 + lane;
-		const uint32_t w = rc[q].y & 0xffffu, h = rc[q].y >> 16;
-		if (i < P) seg[i] = make_uint4(rc[q].x, rc[q].y, id[q], 0u);
-		if (w * h) {
-			const uint32_t x0 = rc[q].x & 0xffffu;
-			atomicAdd(&diff[x0], 1);
-			atomicAdd(&diff[x0 + w], -1);
-			tiles += w * h;
+		for (int q = 0; q < TB_GROUPS; q++) {
+			const int i = block * TB_BLOCK + wave * (64 * TB_GROUPS) + q * 64 + lane;
+			id[q] = i < P ? perm[i] : 0xFFFFFFFFu;
 		}
+#pragma unroll
+		for (int q = 0; q < TB_GROUPS; q++) rc[q] = id[q] != 0xFFFFFFFFu ? rect[id[q]] : make_uint2(0u, 0u);
+		__syncthreads();
+		uint32_t tiles = 0;
+#pragma unroll
+		for (int q = 0; q < TB_GROUPS; q++) {
+			const int i = block * TB_BLOCK + wave * (64 * TB_GROUPS) + q * 64 + lane;
+			const uint32_t w = rc[q].y & 0xffffu, h = rc[q].y >> 16;
+			if (i < P) seg[i] = make_uint4(rc[q].x, rc[q].y, id[q], 0u);
+			if (w * h) {
+				const uint32_t x0 = rc[q].x & 0xffffu;
+				atomicAdd(&diff[x0], 1);
+				atomicAdd(&diff[x0 + w], -1);
+				tiles += w * h;
+			}
+		}
+		__syncthreads();
+		// difference array (+1 at the first column, -1 behind the last) -> prefix sum over the digits = pairs per column
+		const uint32_t c = (uint32_t)diff[threadIdx.x];
+		const uint32_t cnt = gsr_excl_scan_256(c, wsum) + c;   // (wrapping arithmetic: the prefix sums themselves are >= 0)
+		table[(size_t)block * TB_RADIX + threadIdx.x] = cnt;
+		acc += cnt;
+		uint32_t tot;
+		(void)gsr_excl_scan_256(tiles, wsum, &tot);   // (ends with a barrier: diff may be rewritten)
+		if (threadIdx.x == 0) block_sums[block] = tot;
 	}
-	__syncthreads();
-	tb_publish_histogram(diff, wsum, (int)blockIdx.x, table, chunk_sums, nchunks, nchunks);
-	uint32_t tot;
-	(void)gsr_excl_scan_256(tiles, wsum, &tot);
-	if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
+	if (acc) {
+		atomicAdd(&chunk_sums[(size_t)(block0 / GSR_SORT_CHUNK) * TB_RADIX + threadIdx.x], acc);
+		if (nchunks > GSR_SORT_CHUNK)
+			atomicAdd(&chunk_sums[(size_t)(nchunks + block0 / (GSR_SORT_CHUNK * GSR_SORT_CHUNK)) * TB_RADIX + threadIdx.x], acc);
+	}
 }
 
 // ---- pass 1, scatter ------------------------------------------------------------------------------
@@ -358,6 +357,11 @@ __device__ __forceinline__ void tb_row_map(const uint32_t* __restrict__ col_tota
 	__syncthreads();
 }
 
+// Persistent: workgroup w takes the CONSECUTIVE blocks [w per, (w + 1) per) and adds to the chunk (and super-chunk) sums once per
+// run of blocks inside one chunk (super-chunk), from registers, instead of once per block: every atomic on those rows has up to
+// 64 (4 096) adders per address, which serialise in the L2 (C5, 20 600 blocks: the kernel took 0.15 ms for 168 MB).  (A ticket
+// per chunk -- the last block of a chunk adds the finished chunk row -- needs device-scope fences, which write back and
+// invalidate an XCD's whole L2 on this chip: 0.15 -> 1.4 ms, measured.)
 __global__ void __launch_bounds__(TB_THREADS) gsr_tb_row_hist_kernel(const uint32_t* __restrict__ col_totals, const uint2* __restrict__ cpair,
                                                                      uint32_t* __restrict__ table, uint32_t* __restrict__ chunk_sums, int chunk_rows)
 {
@@ -366,8 +370,11 @@ __global__ void __launch_bounds__(TB_THREADS) gsr_tb_row_hist_kernel(const uint3
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	tb_row_map(col_totals, s_bstart, s_cstart, wsum);
 	const uint32_t nblocks = s_bstart[TB_RADIX];
-	const int nchunks = (int)((nblocks + GSR_SORT_CHUNK - 1) / GSR_SORT_CHUNK);
-	for (uint32_t eb = blockIdx.x; eb < nblocks; eb += gridDim.x) {
+	const bool three_level = (nblocks + GSR_SORT_CHUNK - 1) / GSR_SORT_CHUNK > GSR_SORT_CHUNK;
+	const uint32_t per = (nblocks + gridDim.x - 1) / gridDim.x;
+	const uint32_t eb_first = blockIdx.x * per, eb_end = min(eb_first + per, nblocks);
+	uint32_t acc_chunk = 0u, acc_super = 0u;   // thread d: digit d's count over the blocks of the current chunk / super-chunk
+	for (uint32_t eb = eb_first; eb < eb_end; eb++) {
 		if (s_bstart[threadIdx.x] <= eb && eb < s_bstart[threadIdx.x + 1]) s_x = threadIdx.x;
 		diff[threadIdx.x] = 0;
 		if (threadIdx.x < 4) diff[TB_RADIX + threadIdx.x] = 0;
@@ -388,8 +395,20 @@ __global__ void __launch_bounds__(TB_THREADS) gsr_tb_row_hist_kernel(const uint3
 				atomicAdd(&diff[y0 + h], -1);
 			}
 		__syncthreads();
-		tb_publish_histogram(diff, wsum, (int)eb, table, chunk_sums, nchunks, chunk_rows);
-		__syncthreads();   // s_x, diff: the next round writes them
+		const uint32_t c = (uint32_t)diff[threadIdx.x];
+		const uint32_t cnt = gsr_excl_scan_256(c, wsum) + c;   // (ends with a barrier: s_x and diff may be rewritten)
+		table[(size_t)eb * TB_RADIX + threadIdx.x] = cnt;
+		acc_chunk += cnt;
+		if (eb + 1 == eb_end || (eb + 1) % GSR_SORT_CHUNK == 0) {   // the run inside this chunk ends
+			if (acc_chunk) atomicAdd(&chunk_sums[(size_t)(eb / GSR_SORT_CHUNK) * TB_RADIX + threadIdx.x], acc_chunk);
+			acc_super += acc_chunk;
+			acc_chunk = 0u;
+			if (three_level && (eb + 1 == eb_end || (eb + 1) % (GSR_SORT_CHUNK * GSR_SORT_CHUNK) == 0)) {
+				if (acc_super) atomicAdd(&chunk_sums[(size_t)(chunk_rows + eb / (GSR_SORT_CHUNK * GSR_SORT_CHUNK)) * TB_RADIX + threadIdx.x], acc_super);
+				acc_super = 0u;
+			}
+			if (!three_level) acc_super = 0u;
+		}
 	}
 }
 
@@ -482,8 +501,10 @@ static TbColTable tb_col_table(void* mem, int P)
 void gsr_launch_tilebin_col_hist(GsrGeometry g, int P, int result_in_alt, hipStream_t s)
 {
 	const TbColTable t = tb_col_table(g.col_table, P);
-	hipLaunchKernelGGL(gsr_tb_col_hist_kernel, dim3(t.nblocks), dim3(TB_THREADS), 0, s, result_in_alt ? g.perm_alt : g.perm, g.rect, P,
-	                   g.sorted_block_sums, t.table, t.chunk_sums, t.nchunks, t.seg, g.status, (uint32_t)result_in_alt);
+	int per = 1;   // consecutive blocks per workgroup: 1 up to 2 048 blocks, then as many as keep >= 1 024 workgroups
+	while (per < GSR_SORT_CHUNK && t.nblocks / (2 * per) >= 1024) per *= 2;
+	hipLaunchKernelGGL(gsr_tb_col_hist_kernel, dim3((t.nblocks + per - 1) / per), dim3(TB_THREADS), 0, s, result_in_alt ? g.perm_alt : g.perm, g.rect, P,
+	                   g.sorted_block_sums, t.table, t.nblocks, t.chunk_sums, t.nchunks, t.seg, g.status, (uint32_t)result_in_alt, per);
 }
 
 // the sorted column pairs: 8 bytes each, in the two arrays of the binning blob that only the tile sort uses (point_list_alt and,
