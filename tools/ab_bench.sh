@@ -9,6 +9,6 @@ for v in "$@"; do
     python bench.py --config $c --steps $st --warmup 5 --no-cpu-baseline --no-extras 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.readlines()[-1]); k=d['kernels']
-print('$v', d['config']['workload'].split(':')[0], d['ms_per_step'], d['step_ms']['median'], {n:k[n]['ms'] for n in k if n not in ('preprocess','preprocess_color','binning','gaussian_backward')})"
+print('$v', d['config']['workload'].split(':')[0], d['ms_per_step'], d['step_ms']['median'], {n:k[n]['ms'] for n in k if n not in ('preprocess','preprocess_color','binning')})"
   done
 done
