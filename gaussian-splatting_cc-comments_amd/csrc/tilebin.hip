@@ -266,7 +266,8 @@ __global__ void __launch_bounds__(TB_THREADS) gsr_tb_col_hist_kernel(const uint3
 // Output: column pairs sorted by tile column, inside a column in depth order: (y0 | (h - 1) << 8, Gaussian id) as one 8-byte word.
 // Also: the Gaussians' first gradient slots (slot_base, depth-ordered numbering as before), pass 1's digit totals for pass 2's
 // workgroup map (workgroup 0), and zeroes for pass 2's chunk sums.
-__global__ void __launch_bounds__(TB_THREADS) gsr_tb_col_scatter_kernel(const uint4* __restrict__ seg, int P, const uint32_t* __restrict__ block_sums,
+__global__ void __launch_bounds__(TB_THREADS) gsr_tb_col_scatter_kernel(const uint4* __restrict__ seg, int P, int nblocks,
+                                                                        const uint32_t* __restrict__ block_sums,
                                                                         const uint32_t* __restrict__ table, const uint32_t* __restrict__ chunk_sums,
                                                                         int nchunks, uint32_t* __restrict__ slot_base,
                                                                         uint32_t* __restrict__ col_totals, uint2* __restrict__ cpair, uint32_t capacity,
@@ -281,65 +282,78 @@ __global__ void __launch_bounds__(TB_THREADS) gsr_tb_col_scatter_kernel(const ui
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	for (size_t w = (size_t)blockIdx.x * TB_THREADS + threadIdx.x; w < clear_words; w += (size_t)gridDim.x * TB_THREADS) clear[w] = 0u;
 	s_flag[wave][lane] = 0u;
+	// Workgroup w takes the consecutive blocks [w per, (w + 1) per) -- one block while every block of the launch is resident at once
+	// (up to ~1 M Gaussians), several beyond -- and walks the offset tables for the first of them only (see pass 2's scatter)
+	const int per = (nblocks + (int)gridDim.x - 1) / (int)gridDim.x;
+	const int blk_first = (int)blockIdx.x * per, blk_end = min(blk_first + per, nblocks);
+	if (blk_first >= blk_end) return;   // (uniform)
 
-	uint4 sg[TB_GROUPS];
-#pragma unroll
-	for (int q = 0; q < TB_GROUPS; q++) {
-		const int i = blockIdx.x * TB_BLOCK + wave * (64 * TB_GROUPS) + q * 64 + lane;
-		sg[q] = i < P ? seg[i] : make_uint4(0u, 0u, 0u, 0u);
-	}
-	// tile count of all workgroups in front (depth order): every workgroup adds the block sums up itself
+	// tile count of all blocks in front (depth order): every workgroup adds the block sums up itself
 	uint32_t before_tiles = 0;
-	for (uint32_t b0 = 0; b0 < blockIdx.x; b0 += 8 * TB_THREADS) {
+	for (uint32_t b0 = 0; b0 < (uint32_t)blk_first; b0 += 8 * TB_THREADS) {
 		uint32_t t[8];
 #pragma unroll
 		for (int j = 0; j < 8; j++) {
 			const uint32_t b = b0 + j * TB_THREADS + threadIdx.x;
-			t[j] = b < blockIdx.x ? block_sums[b] : 0u;
+			t[j] = b < (uint32_t)blk_first ? block_sums[b] : 0u;
 		}
 #pragma unroll
 		for (int j = 0; j < 8; j++) before_tiles += t[j];
 	}
 	uint32_t v, before;
-	gsr_radix_walk_256<TB_WALK_ROWS>(table, chunk_sums, nchunks, nchunks, (int)blockIdx.x, reinterpret_cast<uint32_t*>(&s_mask[0][0]), v, before);
+	gsr_radix_walk_256<TB_WALK_ROWS>(table, chunk_sums, nchunks, nchunks, blk_first, reinterpret_cast<uint32_t*>(&s_mask[0][0]), v, before);
 	if (blockIdx.x == 0) col_totals[threadIdx.x] = v;
-	const uint32_t gbase = gsr_excl_scan_256(v, wsum) + before;
+	const uint32_t dbase = gsr_excl_scan_256(v, wsum);
 	uint32_t tiles_front;
 	(void)gsr_excl_scan_256(before_tiles, wsum, &tiles_front);   // (its sum over the threads)
-
-	uint32_t id[TB_GROUPS], d0[TB_GROUPS], len[TB_GROUPS], key[TB_GROUPS], tiles[TB_GROUPS], incl_t[TB_GROUPS];
-#pragma unroll
-	for (int q = 0; q < TB_GROUPS; q++) {
-		const uint32_t w = sg[q].y & 0xffffu, h = sg[q].y >> 16;
-		id[q] = sg[q].z;
-		tiles[q] = w * h;
-		len[q] = tiles[q] ? w : 0u;
-		d0[q] = sg[q].x & 0xffffu;
-		key[q] = (sg[q].x >> 16) | ((h - 1u) << 8);
-		incl_t[q] = tb_wave_incl_scan(tiles[q]);
-		if (lane == 63) gsum[wave * TB_GROUPS + q] = incl_t[q];
-	}
-	tb_wave_counts(d0, len, wdiff[wave], wcount[wave]);
-	__syncthreads();
-	// the peer masks start at zero (the walk's partial sums lay there)
-	reinterpret_cast<uint4*>(s_mask[wave])[lane] = make_uint4(0u, 0u, 0u, 0u);
-	reinterpret_cast<uint4*>(s_mask[wave])[64 + lane] = make_uint4(0u, 0u, 0u, 0u);
-	tb_wave_bases(wcount, gbase);
-	// first gradient slot of every Gaussian with tiles = tiles of everything in front of it in depth order
-#pragma unroll
-	for (int q = 0; q < TB_GROUPS; q++) {
-		uint32_t base = tiles_front;
-		for (int G = 0; G < wave * TB_GROUPS + q; G++) base += gsum[G];
-		if (tiles[q]) slot_base[id[q]] = base + incl_t[q] - tiles[q];
-	}
-	__syncthreads();
 	uint32_t round = 0u;
+
+	for (int blk = blk_first; blk < blk_end; blk++) {
+		if (blk != blk_first) {   // the predecessor's own counts move the offsets on
+			before += table[(size_t)(blk - 1) * TB_RADIX + threadIdx.x];
+			tiles_front += block_sums[blk - 1];
+		}
+		const uint32_t gbase = dbase + before;
+		uint4 sg[TB_GROUPS];
+#pragma unroll
+		for (int q = 0; q < TB_GROUPS; q++) {
+			const int i = blk * TB_BLOCK + wave * (64 * TB_GROUPS) + q * 64 + lane;
+			sg[q] = i < P ? seg[i] : make_uint4(0u, 0u, 0u, 0u);
+		}
+		uint32_t id[TB_GROUPS], d0[TB_GROUPS], len[TB_GROUPS], key[TB_GROUPS], tiles[TB_GROUPS], incl_t[TB_GROUPS];
+#pragma unroll
+		for (int q = 0; q < TB_GROUPS; q++) {
+			const uint32_t w = sg[q].y & 0xffffu, h = sg[q].y >> 16;
+			id[q] = sg[q].z;
+			tiles[q] = w * h;
+			len[q] = tiles[q] ? w : 0u;
+			d0[q] = sg[q].x & 0xffffu;
+			key[q] = (sg[q].x >> 16) | ((h - 1u) << 8);
+			incl_t[q] = tb_wave_incl_scan(tiles[q]);
+			if (lane == 63) gsum[wave * TB_GROUPS + q] = incl_t[q];
+		}
+		tb_wave_counts(d0, len, wdiff[wave], wcount[wave]);
+		__syncthreads();
+		// the peer masks start at zero (the walk's partial sums lay there)
+		reinterpret_cast<uint4*>(s_mask[wave])[lane] = make_uint4(0u, 0u, 0u, 0u);
+		reinterpret_cast<uint4*>(s_mask[wave])[64 + lane] = make_uint4(0u, 0u, 0u, 0u);
+		tb_wave_bases(wcount, gbase);
+		// first gradient slot of every Gaussian with tiles = tiles of everything in front of it in depth order
+#pragma unroll
+		for (int q = 0; q < TB_GROUPS; q++) {
+			uint32_t base = tiles_front;
+			for (int G = 0; G < wave * TB_GROUPS + q; G++) base += gsum[G];
+			if (tiles[q]) slot_base[id[q]] = base + incl_t[q] - tiles[q];
+		}
+		__syncthreads();
 #pragma unroll 1
-	for (int q = 0; q < TB_GROUPS; q++)
-		tb_expand_group(d0[q], len[q], key[q], id[q], s_own[wave], s_flag[wave], round, s_mask[wave], wcount[wave],
-		                [&](uint32_t pos, uint32_t a, uint32_t b) {
-			                if (pos < capacity) cpair[pos] = make_uint2(a, b);   // always true for consistent tables; a corrupted table must not turn into a wild store
-		                });
+		for (int q = 0; q < TB_GROUPS; q++)
+			tb_expand_group(d0[q], len[q], key[q], id[q], s_own[wave], s_flag[wave], round, s_mask[wave], wcount[wave],
+			                [&](uint32_t pos, uint32_t a, uint32_t b) {
+				                if (pos < capacity) cpair[pos] = make_uint2(a, b);   // always true for consistent tables; a corrupted table must not turn into a wild store
+			                });
+		__syncthreads();   // every LDS array is rewritten by the next block
+	}
 }
 
 // ---- pass 2: the map from workgroup to (tile column, first pair) ----------------------------------------
@@ -533,7 +547,8 @@ static int tb_persistent_grid(size_t blocks_max)
 void gsr_launch_tilebin_col_scatter(GsrGeometry g, int P, GsrBinning b, int64_t R, hipStream_t s)
 {
 	const TbColTable t = tb_col_table(g.col_table, P);
-	hipLaunchKernelGGL(gsr_tb_col_scatter_kernel, dim3(t.nblocks), dim3(TB_THREADS), 0, s, t.seg, P, g.sorted_block_sums, t.table, t.chunk_sums,
+	const int grid = t.nblocks < 256 * 4 ? t.nblocks : 256 * 4;   // what the chip holds at once (116 VGPRs: four workgroups per CU)
+	hipLaunchKernelGGL(gsr_tb_col_scatter_kernel, dim3(grid), dim3(TB_THREADS), 0, s, t.seg, P, t.nblocks, g.sorted_block_sums, t.table, t.chunk_sums,
 	                   t.nchunks, g.slot_base, t.totals, tb_pairs(b), tb_pair_capacity(b), (uint32_t*)b.sort_table,
 	                   gsr_tilebin_row_clear_words((size_t)R));
 }
