@@ -177,3 +177,23 @@ def test_binning_at_the_256_tile_limit_of_the_column_pairs(W, H):
     bl = _C.binning_layout(P, 1000, W, H)
     assert int(bl.column_pairs) == (1 if (W + 15) // 16 <= 256 and (H + 15) // 16 <= 256 else 0)
     _binning_pair(scene, cam, D, None, f"{W}x{H}")
+
+
+def test_column_pairs_with_splats_that_cover_256_tile_columns_and_rows():
+    """The longest runs the two passes can meet: a 4096 x 4096 image (256 x 256 tiles) with a few splats whose rectangles span
+    every tile column and every tile row (runs of 256 in both passes, 65 536 instances per splat), among small ones."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    P, D, W, H = 40, 0, 4096, 4096
+    scene = gsr_scene.make_scene(P, -3.0, sh_degree=D, seed=77)
+    scales = scene.scales.clone()
+    scales[:3] = torch.tensor([[2.5, 2.5, 0.3], [3.0, 0.8, 0.5], [0.4, 3.5, 0.4]])   # screen-filling, a wide and a tall one
+    means = scene.means3D.clone()
+    means[:3] = torch.tensor([[0.0, 0.0, 0.5], [0.1, -0.2, 1.0], [-0.3, 0.1, 0.0]])
+    opac = scene.opacities.clone()
+    opac[:3] = 0.05
+    scene = scene._replace(scales=scales.contiguous(), means3D=means.contiguous(), opacities=opac.contiguous())
+    cam = gsr_scene.make_camera(W, H, fovx=1.2)
+    o = _binning_pair(scene, cam, D, None, "giant")
+    rect_tiles = o["tiles_touched"].max()
+    assert int(rect_tiles) == 256 * 256, int(rect_tiles)
