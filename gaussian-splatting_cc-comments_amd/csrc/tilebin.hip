@@ -25,8 +25,9 @@
 //     in LDS + a running maximum over the lanes, as the key emission of binning.hip did), ranks the 64 elements of a round
 //     by digit through LDS peer masks (ds_or_b64, as sort.hip), and stores each element at its final global position.
 // Pass 2's workgroups are column-aligned (a workgroup never spans two tile columns; the map from workgroup to (column, offset)
-// is a 256-entry prefix sum every workgroup takes from pass 1's digit totals) and its kernels are persistent grid-stride
-// loops, because only the device knows how many column pairs there are.
+// is a 256-entry prefix sum every workgroup takes from pass 1's digit totals) and its kernels are persistent -- a fixed grid,
+// every workgroup a run of consecutive blocks -- because only the device knows how many column pairs there are.  Consecutive
+// blocks also let a workgroup add to the tables' chunk sums once per run (histograms) and walk the tables once (scatters).
 //
 // Measured and not kept (C3, MI355X; the scatter kernels are bound by their LDS instruction stream -- the LDS unit of a CU is
 // busy 35-45 % of their duration -- and by dependent global round trips, not by bytes): elements staged in LDS in digit
