@@ -37,7 +37,10 @@ __global__ void __launch_bounds__(64 * GSR_WAVES_PER_WG) __attribute__((amdgpu_w
 {
 	// per-wave staging of the surviving instances of a batch.  Every per-instance scalar that meets the
 	// float2 pixel pairs is stored TWICE, so a ds_read_b128 delivers it as an aligned register pair ready
-	// for v_pk_*_f32 (the compiler otherwise spends one v_mov per scalar per instance on the duplication)
+	// for v_pk_*_f32 (the compiler otherwise spends one v_mov per scalar per instance on the duplication).
+	// (ROCm 7.2's compiler does fold a splat into op_sel / op_sel_hi for most packed operands by now; re-measured in round 3
+	// with every scalar stored once -- three ds_read_b128 per instance instead of five and a dword, 119 VGPRs: 0.467 ->
+	// 0.476 ms at C3, 1.616 -> 1.633 at C5, results identical.  The duplicated layout stays.)
 	__shared__ float4 s_rec[GSR_WAVES_PER_WG][5][64];
 	__shared__ uint32_t s_bands[GSR_WAVES_PER_WG][64];
 	// transposition area of the per-instance wave reduction: lane l stores its eight partials at row l (row stride 9 words:
