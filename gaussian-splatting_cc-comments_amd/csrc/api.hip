@@ -320,6 +320,8 @@ struct GsrThreadDevice {
 	hipEvent_t aux_fork = nullptr, aux_join = nullptr;
 	uint32_t* status_host = nullptr;
 	hipEvent_t status_event = nullptr;
+	hipStream_t copy_stream = nullptr;   // the count's read-back travels beside the depth sort, not in front of it
+	hipEvent_t copy_fork = nullptr;
 };
 struct GsrThreadState { GsrThreadDevice dev[GSR_MAX_DEVICES]; };
 static thread_local GsrThreadState g_thread;
@@ -336,6 +338,8 @@ extern "C" int gsr_thread_release(void)
 		if (t.aux_fork && hipEventDestroy(t.aux_fork) != hipSuccess) rc = GSR_ERR_HIP;
 		if (t.aux_join && hipEventDestroy(t.aux_join) != hipSuccess) rc = GSR_ERR_HIP;
 		if (t.status_event && hipEventDestroy(t.status_event) != hipSuccess) rc = GSR_ERR_HIP;
+		if (t.copy_stream) { (void)hipStreamSynchronize(t.copy_stream); if (hipStreamDestroy(t.copy_stream) != hipSuccess) rc = GSR_ERR_HIP; }
+		if (t.copy_fork && hipEventDestroy(t.copy_fork) != hipSuccess) rc = GSR_ERR_HIP;
 		if (t.status_host && hipHostFree(t.status_host) != hipSuccess) rc = GSR_ERR_HIP;
 		t = GsrThreadDevice();
 	}
@@ -473,8 +477,36 @@ static int gsr_forward_preprocess_impl(int P, int D, int M, int width, int heigh
 	}
 	uint32_t* status_host = td.status_host;
 	hipEvent_t ev = td.status_event;
-	if ((rc = gsr_check_hip(hipMemcpyAsync(status_host, a.g.status, GSR_STATUS_WORDS * 4, hipMemcpyDeviceToHost, s), "hipMemcpyAsync(num_rendered)"))) return rc;
-	if ((rc = gsr_check_hip(hipEventRecord(ev, s), "hipEventRecord"))) return rc;
+	// The copy (a 6 us blit + the record of its event) goes to a stream of its own behind the geometry kernel, so that the depth
+	// sort's first launch follows that kernel directly (13 us of `stream`'s critical path at C3); the host waits for the copy's
+	// event before this call returns, so nothing of it outlives the call.  In line with GSR_DEBUG_SYNC / GSR_DEBUG_SERIAL, when
+	// every stage is being timed, or when the stream cannot be had.
+	bool copy_beside = !(debug & (GSR_DEBUG_SYNC | GSR_DEBUG_SERIAL)) && !gsr_prof_records_all(s);
+	if (copy_beside && !td.copy_stream) {
+		hipStream_t st = nullptr;
+		hipEvent_t f = nullptr;
+		if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&f, hipEventDisableTiming) == hipSuccess) {
+			td.copy_stream = st; td.copy_fork = f;
+		} else {
+			(void)hipGetLastError();
+			if (st) (void)hipStreamDestroy(st);
+			if (f) (void)hipEventDestroy(f);
+			copy_beside = false;
+		}
+	}
+	if (copy_beside) {
+		if ((rc = gsr_check_hip(hipEventRecord(td.copy_fork, s), "hipEventRecord(copy fork)"))) return rc;
+		if ((rc = gsr_check_hip(hipStreamWaitEvent(td.copy_stream, td.copy_fork, 0), "hipStreamWaitEvent(copy fork)"))) return rc;
+	}
+	hipStream_t cs = copy_beside ? td.copy_stream : s;
+	if ((rc = gsr_check_hip(hipMemcpyAsync(status_host, a.g.status, GSR_STATUS_WORDS * 4, hipMemcpyDeviceToHost, cs), "hipMemcpyAsync(num_rendered)"))) {
+		if (copy_beside) (void)hipStreamSynchronize(td.copy_stream);
+		return rc;
+	}
+	if ((rc = gsr_check_hip(hipEventRecord(ev, cs), "hipEventRecord"))) {
+		if (copy_beside) (void)hipStreamSynchronize(td.copy_stream);   // the copy must not outlive the call
+		return rc;
+	}
 	// The depth sort orders key - min (keys = float bits of the view-space depth; min / max: partial maxima in the status
 	// words, reduced by every sort workgroup).  Its first three 8-bit passes are always needed and are enqueued at once;
 	// whether bits 24..31 of max - min are populated is known once the status block has landed on the host.

@@ -58,8 +58,8 @@ const char* gsr_last_error(void);
 const char* gsr_version(void);
 
 /* Frees what the calling host thread's earlier calls created and kept for reuse: per device one helper stream with
- * its two events, one pinned 784-byte landing buffer for the instance count and its event (all created on first use
- * by gsr_forward_preprocess*).  Optional -- a later call simply creates them again; meant for worker threads that
+ * its two events, one stream + event for the read-back of the instance count, one pinned 784-byte landing buffer for it and
+ * its event (all created on first use by gsr_forward_preprocess*).  Optional -- a later call simply creates them again; meant for worker threads that
  * end, and for leak checkers.  Call it when none of this thread's library calls is still executing. */
 int gsr_thread_release(void);
 
@@ -136,7 +136,9 @@ int gsr_binning_layout_of(int P, int64_t num_rendered, int width, int height, gs
  * per host thread and device, non-blocking, forked from and joined into `stream` with events) beside the geometry
  * kernel and the depth sort; GSR_DEBUG_SERIAL or GSR_DEBUG_SYNC in `debug` and an all-stages gsr_profile_begin() keep
  * it on `stream`.  Every return of the call, error returns included, leaves `stream` ordered after the helper stream's
- * work, so `geometry` may be released or reused on `stream` as soon as the call has returned.
+ * work, so `geometry` may be released or reused on `stream` as soon as the call has returned.  The read-back of the count
+ * travels on a second library stream behind the geometry kernel (beside the depth sort, not in front of it); the host has
+ * waited for it when the call returns.
  */
 int gsr_forward_preprocess(
 	int P, int D, int M,
