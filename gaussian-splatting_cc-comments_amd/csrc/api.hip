@@ -455,9 +455,27 @@ static int gsr_forward_preprocess_impl(int P, int D, int M, int width, int heigh
 		join.arm(td.aux_join);
 	}
 	if ((rc = gsr_check_hip(hipMemsetAsync(a.g.status, 0, GSR_STATUS_WORDS * 4, s), "hipMemsetAsync(status)"))) return rc;
+	// The count's read-back (a 6 us blit) goes to a stream of its own behind the geometry kernel, so that the depth sort's first
+	// launch follows that kernel directly; the stream waits for an event that the geometry kernel's own dispatch packet signals
+	// (hipExtLaunchKernelGGL) -- a hipEventRecord behind the kernel is a barrier packet and cost the sort's first launch ~8 us.
+	// The host waits for the copy before this call returns, so nothing of it outlives the call.  In line with GSR_DEBUG_SYNC /
+	// GSR_DEBUG_SERIAL, when every stage is being timed, or when the stream cannot be had.
+	bool copy_beside = !(debug & (GSR_DEBUG_SYNC | GSR_DEBUG_SERIAL)) && !gsr_prof_records_all(s);
+	if (copy_beside && !td.copy_stream) {
+		hipStream_t st = nullptr;
+		hipEvent_t f = nullptr;
+		if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&f, hipEventDisableTiming) == hipSuccess) {
+			td.copy_stream = st; td.copy_fork = f;
+		} else {
+			(void)hipGetLastError();
+			if (st) (void)hipStreamDestroy(st);
+			if (f) (void)hipEventDestroy(f);
+			copy_beside = false;
+		}
+	}
 	{
 		GsrProfScope p(s, "preprocess");
-		gsr_launch_preprocess(a, s);
+		gsr_launch_preprocess(a, s, copy_beside ? td.copy_fork : nullptr);
 	}
 	if ((rc = gsr_stage_done(s, debug, "preprocess"))) return rc;
 	if (color && !beside) {
@@ -477,27 +495,7 @@ static int gsr_forward_preprocess_impl(int P, int D, int M, int width, int heigh
 	}
 	uint32_t* status_host = td.status_host;
 	hipEvent_t ev = td.status_event;
-	// The copy (a 6 us blit + the record of its event) goes to a stream of its own behind the geometry kernel, so that the depth
-	// sort's first launch follows that kernel directly (13 us of `stream`'s critical path at C3); the host waits for the copy's
-	// event before this call returns, so nothing of it outlives the call.  In line with GSR_DEBUG_SYNC / GSR_DEBUG_SERIAL, when
-	// every stage is being timed, or when the stream cannot be had.
-	bool copy_beside = !(debug & (GSR_DEBUG_SYNC | GSR_DEBUG_SERIAL)) && !gsr_prof_records_all(s);
-	if (copy_beside && !td.copy_stream) {
-		hipStream_t st = nullptr;
-		hipEvent_t f = nullptr;
-		if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&f, hipEventDisableTiming) == hipSuccess) {
-			td.copy_stream = st; td.copy_fork = f;
-		} else {
-			(void)hipGetLastError();
-			if (st) (void)hipStreamDestroy(st);
-			if (f) (void)hipEventDestroy(f);
-			copy_beside = false;
-		}
-	}
-	if (copy_beside) {
-		if ((rc = gsr_check_hip(hipEventRecord(td.copy_fork, s), "hipEventRecord(copy fork)"))) return rc;
-		if ((rc = gsr_check_hip(hipStreamWaitEvent(td.copy_stream, td.copy_fork, 0), "hipStreamWaitEvent(copy fork)"))) return rc;
-	}
+	if (copy_beside && (rc = gsr_check_hip(hipStreamWaitEvent(td.copy_stream, td.copy_fork, 0), "hipStreamWaitEvent(copy fork)"))) return rc;
 	hipStream_t cs = copy_beside ? td.copy_stream : s;
 	if ((rc = gsr_check_hip(hipMemcpyAsync(status_host, a.g.status, GSR_STATUS_WORDS * 4, hipMemcpyDeviceToHost, cs), "hipMemcpyAsync(num_rendered)"))) {
 		if (copy_beside) (void)hipStreamSynchronize(td.copy_stream);

@@ -6,6 +6,7 @@
 // kernel also accumulates the instance count (num_rendered) -- one atomic add per workgroup into 64
 // partial counters -- so no scan over P follows.
 #include "gsr_internal.h"
+#include <hip/hip_ext.h>
 
 // forward.cu:21-81 computeColorFromSH, one channel at a time in the glm::vec3 expression order
 __device__ __forceinline__ float gsr_sh_channel(int deg, const float* sh, int ch, float x, float y, float z)
@@ -246,13 +247,20 @@ __global__ void __launch_bounds__(GSR_PREPROCESS_BLOCK) gsr_preprocess_color_ker
 	reinterpret_cast<float4*>(a.g.splat + idx)[2] = make_float4(rgb[0], rgb[1], rgb[2], 0.f);   // the record's last 16 bytes: one aligned store per lane
 }
 
-void gsr_launch_preprocess(const GsrPreprocessArgs& a, hipStream_t s)
+// done: optional event signalled by the kernel's own dispatch packet when it has finished (hipExtLaunchKernelGGL): a separate
+// hipEventRecord behind the kernel is a barrier packet of its own and costs the stream's next launch ~8 us
+void gsr_launch_preprocess(const GsrPreprocessArgs& a, hipStream_t s, hipEvent_t done)
 {
 	const int nb = (a.P + GSR_PREPROCESS_BLOCK - 1) / GSR_PREPROCESS_BLOCK;
 	uint32_t* clear = (uint32_t*)a.g.sort_table;
 	const size_t clear_words = gsr_radix_clear_words((size_t)a.P);
 	uint32_t* clear2 = (uint32_t*)a.g.col_table;
 	const size_t clear2_words = gsr_tilebin_col_clear_words((size_t)a.P);
+	if (done) {
+		if (a.leaf) hipExtLaunchKernelGGL(gsr_preprocess_kernel<true>, dim3(nb), dim3(GSR_PREPROCESS_BLOCK), 0, s, nullptr, done, 0, a, clear, clear_words, clear2, clear2_words);
+		else hipExtLaunchKernelGGL(gsr_preprocess_kernel<false>, dim3(nb), dim3(GSR_PREPROCESS_BLOCK), 0, s, nullptr, done, 0, a, clear, clear_words, clear2, clear2_words);
+		return;
+	}
 	if (a.leaf) hipLaunchKernelGGL(gsr_preprocess_kernel<true>, dim3(nb), dim3(GSR_PREPROCESS_BLOCK), 0, s, a, clear, clear_words, clear2, clear2_words);
 	else hipLaunchKernelGGL(gsr_preprocess_kernel<false>, dim3(nb), dim3(GSR_PREPROCESS_BLOCK), 0, s, a, clear, clear_words, clear2, clear2_words);
 }
