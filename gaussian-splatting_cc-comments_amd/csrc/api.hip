@@ -443,9 +443,10 @@ static int gsr_forward_preprocess_impl(int P, int D, int M, int width, int heigh
 	// the caller is free to release or reuse `geometry` on `stream` the moment this call returns (include/gsr.h, stream
 	// contract), and the helper stream may still be writing rgb / clamp bits / sh_ddir into it.
 	GsrJoinOnExit join(s);
+	// The status words start at zero (a one-workgroup kernel); its dispatch packet signals the helper stream's fork event, so the
+	// helper stream starts where the caller's stream stands now (its inputs are ready there) without a barrier packet of its own
+	gsr_launch_zero_status(a.g.status, s, beside ? td.aux_fork : nullptr);
 	if (beside) {
-		// fork: the helper stream starts where the caller's stream stands now (its inputs are ready there)
-		if ((rc = gsr_check_hip(hipEventRecord(td.aux_fork, s), "hipEventRecord(fork)"))) return rc;
 		if ((rc = gsr_check_hip(hipStreamWaitEvent(td.aux_stream, td.aux_fork, 0), "hipStreamWaitEvent(fork)"))) return rc;
 		gsr_launch_preprocess_color(a, td.aux_stream, P <= GSR_COLOR_BESIDE_MAX_P ? GSR_COLOR_BESIDE_LDS : 0);
 		if (hipEventRecord(td.aux_join, td.aux_stream) != hipSuccess) {
@@ -454,7 +455,6 @@ static int gsr_forward_preprocess_impl(int P, int D, int M, int width, int heigh
 		}
 		join.arm(td.aux_join);
 	}
-	if ((rc = gsr_check_hip(hipMemsetAsync(a.g.status, 0, GSR_STATUS_WORDS * 4, s), "hipMemsetAsync(status)"))) return rc;
 	// The count's read-back (a 6 us blit) goes to a stream of its own behind the geometry kernel, so that the depth sort's first
 	// launch follows that kernel directly; the stream waits for an event that the geometry kernel's own dispatch packet signals
 	// (hipExtLaunchKernelGGL) -- a hipEventRecord behind the kernel is a barrier packet and cost the sort's first launch ~8 us.

@@ -247,6 +247,21 @@ __global__ void __launch_bounds__(GSR_PREPROCESS_BLOCK) gsr_preprocess_color_ker
 	reinterpret_cast<float4*>(a.g.splat + idx)[2] = make_float4(rgb[0], rgb[1], rgb[2], 0.f);   // the record's last 16 bytes: one aligned store per lane
 }
 
+// The status words (instance count and depth range as 64-way partial sums / maxima, the prefiltered flag) start at zero.  A kernel
+// of ours instead of hipMemsetAsync (which is a kernel launch too) because its dispatch packet can signal an event
+// (hipExtLaunchKernelGGL): `done` = the fork event of the helper stream -- a hipEventRecord in front of the first kernel is a
+// barrier packet of its own, ~6 us of every forward call.
+__global__ void gsr_zero_status_kernel(uint32_t* __restrict__ status)
+{
+	if (threadIdx.x < GSR_STATUS_WORDS) status[threadIdx.x] = 0u;
+}
+void gsr_launch_zero_status(uint32_t* status, hipStream_t s, hipEvent_t done)
+{
+	static_assert(GSR_STATUS_WORDS <= 256, "one workgroup zeroes the status words");
+	if (done) hipExtLaunchKernelGGL(gsr_zero_status_kernel, dim3(1), dim3(256), 0, s, nullptr, done, 0, status);
+	else hipLaunchKernelGGL(gsr_zero_status_kernel, dim3(1), dim3(256), 0, s, status);
+}
+
 // done: optional event signalled by the kernel's own dispatch packet when it has finished (hipExtLaunchKernelGGL): a separate
 // hipEventRecord behind the kernel is a barrier packet of its own and costs the stream's next launch ~8 us
 void gsr_launch_preprocess(const GsrPreprocessArgs& a, hipStream_t s, hipEvent_t done)

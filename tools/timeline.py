@@ -21,7 +21,7 @@ rows.sort()
 starts = [i for i, r in enumerate(rows) if r[2].startswith("gsr_preprocess_kernel")]
 steps = [rows[a:b] for a, b in zip(starts[:-1], starts[1:])]
 # keep the steps of the most common length (the timed ones; per-kernel-table steps run the colour kernel in line)
-steps = [[r for r in s if not (r[2].startswith("__amd_rocclr_fill") and r is s[-1])] for s in steps]   # the next step's status memset
+steps = [[r for r in s if not ((r[2].startswith("__amd_rocclr_fill") or r[2].startswith("gsr_zero_status")) and r is s[-1])] for s in steps]   # the next step's status zeroing
 steps = [s for s in steps if s and s[-1][2].startswith("gsr_gaussian_backward")]
 n = statistics.mode(len(s) for s in steps)
 steps = [s for s in steps if len(s) == n]
