@@ -81,6 +81,7 @@ int gsr_stage_done(hipStream_t s, int debug, const char* stage);
 // Per-kernel event profiling (api.hip); no-ops unless gsr_profile_begin() was called for this stream.
 void gsr_prof_mark_begin(hipStream_t s, const char* name);
 void gsr_prof_mark_end(hipStream_t s);
+bool gsr_prof_kernel_events(hipStream_t s, const char* name, hipEvent_t* a, hipEvent_t* b);
 
 struct GsrProfScope {
 	hipStream_t s;
@@ -157,7 +158,7 @@ void gsr_launch_render_forward(int W, int H, GsrImage img, const uint32_t* point
 // render_backward.hip
 void gsr_launch_render_backward(int W, int H, GsrImage img, const uint32_t* point_list, const GsrSplat* splat, const float4* checkpoints,
                                 const uint32_t* slot_base, const float* bg, const float* dL_dpix, GsrGradSlot* slots,
-                                uint8_t* slot_valid, bool cull, hipStream_t s);
+                                uint8_t* slot_valid, bool cull, hipStream_t s, hipEvent_t t_start = nullptr, hipEvent_t t_stop = nullptr);   // t_*: taken by the kernel's own dispatch packet
 
 // gaussian_backward.hip
 struct GsrGaussianBackwardArgs {

@@ -13,6 +13,7 @@
 // from the same roundings as in the forward kernel (gsr_pair_power; the forward's pre-halved conic terms give the same
 // bits), so the products the forward formed are the ones undone here.
 #include "render_common.h"
+#include <hip/hip_ext.h>
 
 #define GSR_BWD_NV 9
 typedef float v2f __attribute__((ext_vector_type(2)));
@@ -315,12 +316,18 @@ __global__ void __launch_bounds__(64 * GSR_WAVES_PER_WG) __attribute__((amdgpu_w
 
 void gsr_launch_render_backward(int W, int H, GsrImage img, const uint32_t* point_list, const GsrSplat* splat, const float4* checkpoints,
                                 const uint32_t* slot_base, const float* bg, const float* dL_dpix, GsrGradSlot* slots,
-                                uint8_t* slot_valid, bool cull, hipStream_t s)
+                                uint8_t* slot_valid, bool cull, hipStream_t s, hipEvent_t t_start, hipEvent_t t_stop)
 {
 	const int gx = gsr_grid_x(W), gy = gsr_grid_y(H);
 	const int ntiles = gx * gy;
 	const int nslots = ntiles + (int)gsr_tile_order_max_segments(ntiles);   // whole tiles + the extra entries of heavy tiles' depth segments
 	const int nwg = (nslots + GSR_WAVES_PER_WG - 1) / GSR_WAVES_PER_WG;
+	if (t_start || t_stop) {
+		hipExtLaunchKernelGGL(gsr_render_backward_wave_kernel, dim3(nwg), dim3(64 * GSR_WAVES_PER_WG), 0, s, t_start, t_stop, 0, W, H, gx, nslots,
+		                      img.ranges, point_list, splat, checkpoints, img.final_C, slot_base, bg, img.final_T, img.n_contrib, img.tile_max_contrib,
+		                      img.tile_order, dL_dpix, slots, slot_valid, cull ? 1 : 0);
+		return;
+	}
 	hipLaunchKernelGGL(gsr_render_backward_wave_kernel, dim3(nwg), dim3(64 * GSR_WAVES_PER_WG), 0, s, W, H, gx, nslots,
 	                   img.ranges, point_list, splat, checkpoints, img.final_C, slot_base, bg, img.final_T, img.n_contrib, img.tile_max_contrib,
 	                   img.tile_order, dL_dpix, slots, slot_valid, cull ? 1 : 0);
