@@ -508,8 +508,10 @@ def run_rank(args, rank, world, dev, phase=None, grouped=None):
             return step
         steps = {m: make_step(m) for m in ("compact", "allreduce")}
 
-    def timed(step, nsteps, only=None):
-        """K steps between barriers; per-step times from one event per step boundary (K + 1 records)."""
+    def timed(step, nsteps, only=None, per_step=False):
+        """K steps between barriers.  per_step: one event per step boundary as well (K + 1 records) for the per-step times -- an
+        event record is a barrier packet in the stream (6-8 us in front of the next launch), so the timed region proper runs
+        without them and the per-step distribution comes from a second pass of the same K steps."""
         barrier()
         if not args.dry_run and only is not None:
             _C.profile_begin(only=only)
@@ -518,7 +520,7 @@ def run_rank(args, rank, world, dev, phase=None, grouped=None):
         def mark():
             if args.dry_run:
                 marks.append(time.perf_counter())
-            else:
+            elif per_step:
                 e = torch.cuda.Event(enable_timing=True)
                 e.record()
                 marks.append(e)
@@ -563,11 +565,15 @@ def run_rank(args, rank, world, dev, phase=None, grouped=None):
     # ~5 us; bracketing all stages costs ~80 us per step, 4 % of it) plus one event per step boundary.  The full
     # per-kernel table comes from a second, untimed pass below.
     elapsed, per_step = timed(step, args.steps, only=DOMINANT_STAGE)
+    dom_records = []
+    if not args.dry_run:
+        dom_records = _C.profile_end(capacity=4 * max(args.steps, 1))   # the dominant kernel's launches inside the timed region
+        _, per_step = timed(step, args.steps, per_step=True)            # the per-step distribution: the same K steps once more (see timed())
     if os.environ.get("GSR_BENCH_DUMP_STEPS") == "1" and rank == 0:
         print("per-step ms:", " ".join(f"{x:.3f}" for x in per_step), file=sys.stderr, flush=True)
     dom_times, ktimes, table_steps = [], [], 0
     if not args.dry_run:
-        dom_times = [ms for name, ms in _C.profile_end(capacity=4 * max(args.steps, 1)) if name == DOMINANT_STAGE]
+        dom_times = [ms for name, ms in dom_records if name == DOMINANT_STAGE]
         table_steps = max(3, min(args.steps, 10))
         _C.profile_begin()
         for _ in range(table_steps):
@@ -590,7 +596,8 @@ def run_rank(args, rank, world, dev, phase=None, grouped=None):
     out = dict(metric="train iters/sec (fwd+bwd rasterize) @1980x1080, 1M Gaussians", value=round(world * kviews * args.steps / elapsed, 3),
                unit="it/s", n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(ms_per_step, 4),
                higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
-               step_ms=step_stats(per_step),
+               step_ms=dict(step_stats(per_step) or {}, note="a second pass of the same K steps with one event record per step boundary (each record is a "
+                                                              "barrier packet, 6-8 us in front of the next launch: the timed region runs without them)"),
                settle=dict(steps=settle_steps,
                            note="untimed steps of the same workload before the W warm-up steps (device reaches its steady state: the "
                                 "first ~20 steps of a fresh process run up to 7 % slower); --settle-steps 0 disables"))
