@@ -55,6 +55,8 @@ for k in range(n):
         b = util.hip_forward_backward(scene, cam, D, dpix, debug=_C.DEBUG_TILE_SORT)
         keys = ["color", "radii", "final_T", "n_contrib", "ranges"] + (["point_list"] if a["num_rendered"] > 0 else [])
         diff = [x for x in keys if not np.array_equal(a[x], b[x])] + [x for x in a["grads"] if not np.array_equal(a["grads"][x], b["grads"][x])]
+        if int(a["tiles_touched"].astype(np.int64).sum()) != int(a["num_rendered"]) or int(b["num_rendered"]) != int(a["num_rendered"]):
+            diff.append("num_rendered != sum(tiles_touched): the count was read back before it was complete")
         vis = a["tiles_touched"] > 0   # (slot_base is written for Gaussians with tiles only)
         if not np.array_equal(a["slot_base"][vis], b["slot_base"][vis]):
             diff.append("slot_base")
