@@ -293,6 +293,10 @@ def parse_args():
     ap.add_argument("--settle-steps", type=int, default=60,
                     help="steps run before the W warm-up steps (untimed; 0 = off): lets the device reach its steady state for "
                          "this workload, reported as `settle` in the JSON line")
+    ap.add_argument("--debug-mask", type=int, default=0,
+                    help="diagnostics only: bits of the C ABI's `debug` mask (include/gsr.h GSR_DEBUG_*) passed with every call, e.g. 32 = "
+                         "global radix passes for the depth order, 16 = instance emission + tile sort: A/B of the alternate paths on "
+                         "one box.  Reported in config; the headline line is the run with 0")
     ap.add_argument("--dry-run", action="store_true",
                     help="rehearsal of the N > 1 plumbing WITHOUT the rasterizer (no GPU needed): ranks are spawned, the "
                          "process group is formed and every step runs only the gradient exchange on synthetic buffers")
@@ -476,7 +480,7 @@ def run_rank(args, rank, world, dev, phase=None, grouped=None):
             return GaussianRasterizationSettings(
                 image_height=H, image_width=W, tanfovx=c.tanfovx, tanfovy=c.tanfovy, bg=to(scene.bg), scale_modifier=1.0,
                 viewmatrix=to(c.world_view_transform), projmatrix=to(c.full_proj_transform), sh_degree=D,
-                campos=to(c.camera_center), prefiltered=False, debug=False)
+                campos=to(c.camera_center), prefiltered=False, debug=(args.debug_mask or False))
         all_settings = [settings_of(c) for c in cams]
         settings = all_settings[0]
         rasterizers = [GaussianRasterizer(st) for st in all_settings]
@@ -688,6 +692,8 @@ def run_rank(args, rank, world, dev, phase=None, grouped=None):
                             "would add ~80 us of event drains per step); 'preprocess_color' is timed in line here -- in the "
                             "timed region it runs on the library's helper stream beside 'preprocess' and 'depth_sort', so the "
                             "kernels add up to more than the step")
+    if args.debug_mask:
+        out["config"]["debug_mask"] = args.debug_mask   # a diagnostic run of an alternate path, not the headline
     if world == 1 and not args.no_extras:
         out["loss_l1_ssim"] = bench_loss(state["color"].detach(), dev)
         if not args.no_train_step:

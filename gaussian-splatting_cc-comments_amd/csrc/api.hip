@@ -18,8 +18,13 @@
 // (histogram 6 -> 15 us, scatter 13 -> 25).  Measured at C3: step 1.167 -> 1.160 ms with two workgroups per CU (three: 1.161, one:
 // 1.161).  Only while the colour kernel is the shorter of the two: its time grows with P, the depth sort's barely (C5, 6M
 // Gaussians: colour 0.42 ms against 0.25 ms of sort -- there it keeps the whole chip).
+#ifndef GSR_COLOR_BESIDE_LDS
 #define GSR_COLOR_BESIDE_LDS (40 * 1024)
+#endif
 #define GSR_COLOR_BESIDE_MAX_P 1500000
+#ifndef GSR_COLOR_SPLIT_PCT
+#define GSR_COLOR_SPLIT_PCT 55
+#endif
 
 // ---- errors ------------------------------------------------------------------------------------
 static thread_local char g_err[512] = "";
@@ -341,7 +346,7 @@ static bool aligned16(const void* p) { return ((uintptr_t)p & 15u) == 0; }
 // done with the library returns them with gsr_thread_release().
 struct GsrThreadDevice {
 	hipStream_t aux_stream = nullptr;
-	hipEvent_t aux_fork = nullptr, aux_join = nullptr;
+	hipEvent_t aux_fork = nullptr, aux_join = nullptr, aux_mid = nullptr;
 	uint32_t* status_host = nullptr;
 	hipEvent_t status_event = nullptr;
 	hipStream_t copy_stream = nullptr;   // the count's read-back travels beside the depth sort, not in front of it
@@ -361,6 +366,7 @@ extern "C" int gsr_thread_release(void)
 		if (t.aux_stream) { (void)hipStreamSynchronize(t.aux_stream); if (hipStreamDestroy(t.aux_stream) != hipSuccess) rc = GSR_ERR_HIP; }
 		if (t.aux_fork && hipEventDestroy(t.aux_fork) != hipSuccess) rc = GSR_ERR_HIP;
 		if (t.aux_join && hipEventDestroy(t.aux_join) != hipSuccess) rc = GSR_ERR_HIP;
+		if (t.aux_mid && hipEventDestroy(t.aux_mid) != hipSuccess) rc = GSR_ERR_HIP;
 		if (t.status_event && hipEventDestroy(t.status_event) != hipSuccess) rc = GSR_ERR_HIP;
 		if (t.copy_stream) { (void)hipStreamSynchronize(t.copy_stream); if (hipStreamDestroy(t.copy_stream) != hipSuccess) rc = GSR_ERR_HIP; }
 		if (t.copy_fork && hipEventDestroy(t.copy_fork) != hipSuccess) rc = GSR_ERR_HIP;
@@ -445,21 +451,30 @@ static int gsr_forward_preprocess_impl(int P, int D, int M, int width, int heigh
 	GsrThreadDevice& td = g_thread.dev[device];
 	const bool col_pairs = gsr_tilebin_applies(width, height) && !(debug & GSR_DEBUG_TILE_SORT);   // (stage 2 decides the same way)
 	const bool color = gsr_preprocess_needs_color(a);
+	// Depth order: up to GSR_BUCKET_SORT_MAX_P Gaussians in three launches whatever the depth range (depthsort.hip: top-digit buckets,
+	// then every bucket sorted inside LDS; the result lands in (depth_keys, perm) and the rectangles in depth order come with it).
+	// Beyond, and with GSR_DEBUG_RADIX_DEPTH: the global LSD passes.
+#ifdef GSR_AB_FORCE_RADIX_DEPTH   // (A/B builds: csrc/Makefile `variant`)
+	const bool bucket = false;
+#else
+	const bool bucket = gsr_bucket_sort_applies(P) && !(debug & GSR_DEBUG_RADIX_DEPTH);
+#endif
 	bool beside = color && !(debug & (GSR_DEBUG_SYNC | GSR_DEBUG_SERIAL)) && !gsr_prof_records_all(s);
 	if (beside && !td.aux_stream) {
 		hipStream_t st = nullptr;
-		hipEvent_t f = nullptr, j = nullptr;
+		hipEvent_t f = nullptr, j = nullptr, m = nullptr;
 		// (Measured and not kept, round 3: a lowest-priority helper stream changes nothing -- the depth sort's first histogram
 		// and scatter still take 15 + 25 us beside the colour kernel instead of 6 + 13 alone; a helper stream confined to every
 		// other CU with hipExtStreamCreateWithCUMask made the step 0.16 ms slower.)
 		if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&f, hipEventDisableTiming) == hipSuccess &&
-		    hipEventCreateWithFlags(&j, hipEventDisableTiming) == hipSuccess) {
-			td.aux_stream = st; td.aux_fork = f; td.aux_join = j;
+		    hipEventCreateWithFlags(&j, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&m, hipEventDisableTiming) == hipSuccess) {
+			td.aux_stream = st; td.aux_fork = f; td.aux_join = j; td.aux_mid = m;
 		} else {
 			(void)hipGetLastError();
 			if (st) (void)hipStreamDestroy(st);
 			if (f) (void)hipEventDestroy(f);
 			if (j) (void)hipEventDestroy(j);
+			if (m) (void)hipEventDestroy(m);
 			beside = false;  // no helper stream: the colour kernel runs in line
 		}
 	}
@@ -470,9 +485,18 @@ static int gsr_forward_preprocess_impl(int P, int D, int M, int width, int heigh
 	// The status words start at zero (a one-workgroup kernel); its dispatch packet signals the helper stream's fork event, so the
 	// helper stream starts where the caller's stream stands now (its inputs are ready there) without a barrier packet of its own
 	gsr_launch_zero_status(a.g.status, s, beside ? td.aux_fork : nullptr);
+	// ... in two pieces when the bucket depth sort follows: its three launches are chains of dependent round trips to L2 / HBM, and
+	// beside the colour kernel's streams every round trip takes twice as long (measured at C3: 11 + 28 + 47 us beside it, 6 + 16 +
+	// 31 alone).  The first GSR_COLOR_SPLIT_PCT percent of the colour workgroups run beside the geometry kernel, the rest is
+	// held back until the depth sort's last kernel has finished (an event its own dispatch packet signals) and runs beside the
+	// binning instead.
+	const int color_blocks = (P + GSR_PREPROCESS_BLOCK - 1) / GSR_PREPROCESS_BLOCK;
+	const bool color_split = beside && bucket && P <= GSR_COLOR_BESIDE_MAX_P && GSR_COLOR_SPLIT_PCT < 100;
+	const int color_first = color_split ? (int)((int64_t)color_blocks * GSR_COLOR_SPLIT_PCT / 100) : color_blocks;
+	const size_t color_throttle = P <= GSR_COLOR_BESIDE_MAX_P ? GSR_COLOR_BESIDE_LDS : 0;
 	if (beside) {
 		if ((rc = gsr_check_hip(hipStreamWaitEvent(td.aux_stream, td.aux_fork, 0), "hipStreamWaitEvent(fork)"))) return rc;
-		gsr_launch_preprocess_color(a, td.aux_stream, P <= GSR_COLOR_BESIDE_MAX_P ? GSR_COLOR_BESIDE_LDS : 0);
+		gsr_launch_preprocess_color(a, td.aux_stream, color_throttle, 0, color_first);
 		if (hipEventRecord(td.aux_join, td.aux_stream) != hipSuccess) {
 			(void)hipStreamSynchronize(td.aux_stream);  // no event to wait for: wait on the host instead, then report
 			return gsr_fail(GSR_ERR_HIP, "hipEventRecord(join) failed");
@@ -535,12 +559,26 @@ static int gsr_forward_preprocess_impl(int P, int D, int M, int width, int heigh
 	const uint32_t* bias = a.g.status + GSR_STATUS_NEGMIN;
 	{
 		GsrProfScope p(s, "depth_sort");
-		gsr_radix_sort_passes(a.g.depth_keys, a.g.perm, a.g.depth_keys_alt, a.g.perm_alt, (size_t)P, 32, 4, 0, 3, a.g.sort_table, bias, 4, s);
-		// ... and so are the block sums over the three-pass result (the common case) -- with them, for images the column-pair
-		// binning handles, the histogram of its first pass (tilebin.hip): the stream then holds work until the host, back from
-		// the wait below, has launched stage 2.  A fourth pass redoes them.
-		if (col_pairs) gsr_launch_tilebin_col_hist(a.g, P, 1, s);
-		else gsr_launch_sorted_block_sums(a.g, P, 1, s);
+		if (bucket) {
+			gsr_launch_depth_bucket_sort(a.g, P, col_pairs ? gsr_tilebin_seg(a.g, P) : nullptr, s, color_split ? td.aux_mid : nullptr);
+			if (col_pairs) gsr_launch_tilebin_col_hist(a.g, P, 0, s, true);
+			else gsr_launch_sorted_block_sums(a.g, P, 0, s);
+			if (color_split) {   // the rest of the colour kernel, behind the depth sort; the join event moves behind it
+				if ((rc = gsr_check_hip(hipStreamWaitEvent(td.aux_stream, td.aux_mid, 0), "hipStreamWaitEvent(colour, second piece)"))) return rc;
+				gsr_launch_preprocess_color(a, td.aux_stream, color_throttle, color_first, -1);
+				if ((rc = gsr_check_hip(hipEventRecord(td.aux_join, td.aux_stream), "hipEventRecord(join)"))) {
+					(void)hipStreamSynchronize(td.aux_stream);
+					return rc;
+				}
+			}
+		} else {
+			gsr_radix_sort_passes(a.g.depth_keys, a.g.perm, a.g.depth_keys_alt, a.g.perm_alt, (size_t)P, 32, 4, 0, 3, a.g.sort_table, bias, 4, s);
+			// ... and so are the block sums over the three-pass result (the common case) -- with them, for images the column-pair
+			// binning handles, the histogram of its first pass (tilebin.hip): the stream then holds work until the host, back from
+			// the wait below, has launched stage 2.  A fourth pass redoes them.
+			if (col_pairs) gsr_launch_tilebin_col_hist(a.g, P, 1, s);
+			else gsr_launch_sorted_block_sums(a.g, P, 1, s);
+		}
 	}
 	if ((rc = gsr_stage_done(s, debug, "depth_sort"))) return rc;
 	if ((rc = gsr_check_hip(hipEventSynchronize(ev), "hipEventSynchronize(num_rendered)"))) return rc;
@@ -556,7 +594,7 @@ static int gsr_forward_preprocess_impl(int P, int D, int M, int width, int heigh
 	*num_rendered_host = total;
 	const uint32_t kmin = ~negmin;
 	const uint32_t culled_value = kmax >= kmin ? (kmax - kmin) + 1u : 0u;   // largest biased key (what culled Gaussians sort as)
-	const int fourth = (culled_value >> 24) != 0u || (kmax >= kmin && kmax - kmin == 0xFFFFFFFFu);
+	const int fourth = !bucket && ((culled_value >> 24) != 0u || (kmax >= kmin && kmax - kmin == 0xFFFFFFFFu));
 	// join: everything the caller enqueues after this call comes after the colour kernel too
 	if ((rc = join.now())) return rc;
 	if (fourth) {

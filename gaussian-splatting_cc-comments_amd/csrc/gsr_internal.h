@@ -117,7 +117,7 @@ struct GsrPreprocessArgs {
 void gsr_launch_preprocess(const GsrPreprocessArgs& a, hipStream_t s, hipEvent_t done = nullptr);
 void gsr_launch_zero_status(uint32_t* status, hipStream_t s, hipEvent_t done = nullptr);
 bool gsr_preprocess_needs_color(const GsrPreprocessArgs& a);
-void gsr_launch_preprocess_color(const GsrPreprocessArgs& a, hipStream_t s, size_t throttle = 0);
+void gsr_launch_preprocess_color(const GsrPreprocessArgs& a, hipStream_t s, size_t throttle = 0, int block_first = 0, int block_count = -1);
 void gsr_launch_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8_t* present, hipStream_t s);
 
 // binning.hip
@@ -134,7 +134,9 @@ size_t gsr_tilebin_col_clear_words(size_t P);   // leading words of col_table th
 size_t gsr_tilebin_col_table_bytes(size_t P);
 size_t gsr_tilebin_row_clear_words(size_t R);
 size_t gsr_tilebin_row_table_bytes(size_t R);
-void gsr_launch_tilebin_col_hist(GsrGeometry g, int P, int result_in_alt, hipStream_t s);
+void gsr_launch_tilebin_col_hist(GsrGeometry g, int P, int result_in_alt, hipStream_t s, bool seg_ready = false);
+uint4* gsr_tilebin_seg(GsrGeometry g, int P);
+uint4* gsr_tilebin_recs(GsrGeometry g, int P);
 void gsr_launch_tilebin_col_scatter(GsrGeometry g, int P, GsrBinning b, int64_t R, hipStream_t s);
 void gsr_launch_tilebin_row_hist(GsrGeometry g, int P, GsrBinning b, int64_t R, hipStream_t s);
 void gsr_launch_tilebin_row_scatter(GsrGeometry g, int P, GsrBinning b, int64_t R, uint2* ranges, int W, int H, hipStream_t s);
@@ -147,6 +149,12 @@ void gsr_radix_sort_passes(void* k0, uint32_t* v0, void* k1, uint32_t* v1, size_
                            int pass_first, int pass_count, void* table_mem, const uint32_t* bias, int key_bytes, hipStream_t s);
 void gsr_radix_sort_u32(void* k0, uint32_t* v0, void* k1, uint32_t* v1, size_t n, int nbits_total, void* table_mem,
                         int* result_in_first, int clear_table, int key_bytes, hipStream_t s);
+void gsr_radix_top_pass(const uint32_t* k0, uint32_t* k1, const uint2* rec_in, uint4* rec_out, size_t n, void* table_mem, const uint32_t* bias, hipStream_t s);
+int gsr_radix_top_chunks(size_t n);
+// depthsort.hip: depth order in three launches (top-digit buckets, then every bucket sorted inside LDS) for up to this many Gaussians
+#define GSR_BUCKET_SORT_MAX_P (2 << 20)
+bool gsr_bucket_sort_applies(int P);
+void gsr_launch_depth_bucket_sort(GsrGeometry g, int P, uint4* seg, hipStream_t s, hipEvent_t done = nullptr);   // done: signalled by the last kernel's own dispatch packet
 // bytes per tile key of an instance-sized sort: 2 when every tile id fits 16 bits AND the sort runs the instance-sized
 // kernels (sort.hip), else 4
 int gsr_tile_key_bytes(int ntiles, size_t num_rendered);

@@ -20,6 +20,7 @@
 // passes that cover the bits of max - min (3 instead of 4 for any view whose depth range is below 2^24 float steps).
 #include "gsr_internal.h"
 #include "gsr_radix_walk.h"
+#include "gsr_depth_key.h"
 
 #define GSR_SORT_THREADS 256
 #define GSR_SORT_RADIX 256
@@ -41,32 +42,6 @@
 #ifndef GSR_SORT_HUGE_N
 #define GSR_SORT_HUGE_N (32u << 20)
 #endif
-
-// min / range of the biased keys from the 64 + 64 partial maxima {max(~key)}, {max(key)} (GsrGeometry::status)
-struct GsrKeyBias { uint32_t min, culled; };  // culled = value that stands for 0xFFFFFFFF keys = (max - min) + 1
-__device__ __forceinline__ GsrKeyBias gsr_sort_bias(const uint32_t* __restrict__ bias, uint32_t* lds2)
-{
-	GsrKeyBias kb = {0u, 0xFFFFFFFFu};
-	if (!bias) return kb;  // uniform
-	if (threadIdx.x < 64) {
-		uint32_t nmin = bias[threadIdx.x], mx = bias[64 + threadIdx.x];
-#pragma unroll
-		for (int off = 32; off > 0; off >>= 1) {
-			nmin = max(nmin, (uint32_t)__shfl_xor(nmin, off, 64));
-			mx = max(mx, (uint32_t)__shfl_xor(mx, off, 64));
-		}
-		if (threadIdx.x == 0) { lds2[0] = ~nmin; lds2[1] = mx; }
-	}
-	__syncthreads();
-	const uint32_t mn = lds2[0], mx = lds2[1];
-	kb.min = mn;
-	kb.culled = (mx >= mn) ? (mx - mn) + 1u : 0u;  // no visible Gaussian at all: every key is the culled value
-	return kb;
-}
-__device__ __forceinline__ uint32_t gsr_sort_key(uint32_t k, const GsrKeyBias& kb, bool biased)
-{
-	return biased ? (k == 0xFFFFFFFFu ? kb.culled : k - kb.min) : k;
-}
 
 // element index of item `it` of this lane: each wave owns a contiguous run of 64 * ITEMS elements,
 // visited 64 at a time, so element order == (wave, it, lane) order and loads are coalesced
@@ -114,7 +89,7 @@ __global__ void __launch_bounds__(GSR_SORT_THREADS) gsr_radix_hist_kernel(const 
 #pragma unroll
 				for (int c = 0; c < 4; c++) {
 					if constexpr (sizeof(KeyT) == 4) {
-						atomicAdd(&hist[(gsr_sort_key(w[c], kb, biased) >> shift) & mask], 1u);
+						atomicAdd(&hist[gsr_sort_digit(w[c], kb, biased, shift, mask)], 1u);
 					} else {
 						atomicAdd(&hist[((w[c] & 0xffffu) >> shift) & mask], 1u);
 						atomicAdd(&hist[((w[c] >> 16) >> shift) & mask], 1u);
@@ -126,7 +101,7 @@ __global__ void __launch_bounds__(GSR_SORT_THREADS) gsr_radix_hist_kernel(const 
 #pragma unroll
 			for (int it = 0; it < ITEMS; it++) {
 				const size_t i = gsr_sort_index<ITEMS>(block, wave, it, lane);
-				if (i < n) atomicAdd(&hist[(gsr_sort_key((uint32_t)keys[i], kb, biased) >> shift) & mask], 1u);
+				if (i < n) atomicAdd(&hist[gsr_sort_digit((uint32_t)keys[i], kb, biased, shift, mask)], 1u);
 			}
 		}
 		__syncthreads();
@@ -143,11 +118,14 @@ __global__ void __launch_bounds__(GSR_SORT_THREADS) gsr_radix_hist_kernel(const 
 	}
 }
 
-template <int ITEMS, typename KeyT>
+// REC (first level of the bucket depth sort): every element also carries the 8 bytes rec_in[its index] along, and what is written
+// beside the key is the 16-byte record {rec_in[i].x, rec_in[i].y, value, 0} into rec_out, not the value into vals_out.
+template <int ITEMS, typename KeyT, bool REC = false>
 __global__ void __launch_bounds__(GSR_SORT_THREADS) gsr_radix_scatter_kernel(
 	const KeyT* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, KeyT* __restrict__ keys_out,
 	uint32_t* __restrict__ vals_out, size_t n, int shift, int nbits, const uint32_t* __restrict__ table, int nblocks,
-	const uint32_t* __restrict__ chunk_sums, int nchunks, const uint32_t* __restrict__ bias)
+	const uint32_t* __restrict__ chunk_sums, int nchunks, const uint32_t* __restrict__ bias,
+	const uint2* __restrict__ rec_in = nullptr, uint4* __restrict__ rec_out = nullptr)
 {
 	__shared__ uint32_t wcount[GSR_SORT_THREADS / 64][GSR_SORT_RADIX];  // per-wave digit counts, then local bases
 	__shared__ uint32_t gofs[GSR_SORT_RADIX];                           // global base of a digit minus its local base
@@ -158,6 +136,7 @@ __global__ void __launch_bounds__(GSR_SORT_THREADS) gsr_radix_scatter_kernel(
 	static_assert(KEY_WORDS + TILE >= 2 * (GSR_SORT_THREADS / 64) * GSR_SORT_RADIX, "the walk's partial sums and the ranking's peer masks must fit the staging area");
 	KeyT* const skey = reinterpret_cast<KeyT*>(sstage);
 	uint32_t* const sval = sstage + KEY_WORDS;
+	__shared__ uint2 srec[REC ? TILE : 1];
 	__shared__ uint32_t s_bias[2];
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	const uint32_t mask = (1u << nbits) - 1u;
@@ -173,7 +152,15 @@ __global__ void __launch_bounds__(GSR_SORT_THREADS) gsr_radix_scatter_kernel(
 		const size_t i = gsr_sort_index<ITEMS>(blockIdx.x, wave, it, lane);
 		const bool valid = i < n;
 		key[it] = valid ? (uint32_t)keys_in[i] : 0u;
-		val[it] = valid ? vals_in[i] : 0u;
+		val[it] = valid ? (vals_in ? vals_in[i] : (uint32_t)i) : 0u;   // vals_in == NULL: the identity (first level of the bucket depth sort)
+	}
+	uint2 rec[REC ? ITEMS : 1];
+	if constexpr (REC) {
+#pragma unroll
+		for (int it = 0; it < ITEMS; it++) {
+			const size_t i = gsr_sort_index<ITEMS>(blockIdx.x, wave, it, lane);
+			rec[it] = i < n ? rec_in[i] : make_uint2(0u, 0u);
+		}
 	}
 
 	// global exclusive base of digit d = (sum of totals of smaller digits) + this block's offset in d.  The rows that
@@ -263,7 +250,7 @@ __global__ void __launch_bounds__(GSR_SORT_THREADS) gsr_radix_scatter_kernel(
 	for (int it = 0; it < ITEMS; it++) {
 		const size_t i = gsr_sort_index<ITEMS>(blockIdx.x, wave, it, lane);
 		const bool valid = i < n;
-		const uint32_t d = (gsr_sort_key(key[it], kb, biased) >> shift) & mask;
+		const uint32_t d = gsr_sort_digit(key[it], kb, biased, shift, mask);
 		unsigned long long peers = lanebit;
 		uint32_t old = 0;
 		if (valid) {
@@ -313,9 +300,10 @@ __global__ void __launch_bounds__(GSR_SORT_THREADS) gsr_radix_scatter_kernel(
 	for (int it = 0; it < ITEMS; it++) {
 		const size_t i = gsr_sort_index<ITEMS>(blockIdx.x, wave, it, lane);
 		if (i < n) {
-			const uint32_t lp = mycount[(gsr_sort_key(key[it], kb, biased) >> shift) & mask] + rank[it];
+			const uint32_t lp = mycount[gsr_sort_digit(key[it], kb, biased, shift, mask)] + rank[it];
 			skey[lp] = key[it];
 			sval[lp] = val[it];
+			if constexpr (REC) srec[lp] = rec[it];
 		}
 	}
 	__syncthreads();
@@ -323,10 +311,11 @@ __global__ void __launch_bounds__(GSR_SORT_THREADS) gsr_radix_scatter_kernel(
 	const uint32_t count = (uint32_t)((n - first < (size_t)TILE) ? (n - first) : (size_t)TILE);
 	for (uint32_t i = threadIdx.x; i < count; i += GSR_SORT_THREADS) {
 		const KeyT k = skey[i];
-		const uint32_t dst = gofs[(gsr_sort_key((uint32_t)k, kb, biased) >> shift) & mask] + i;
+		const uint32_t dst = gofs[gsr_sort_digit((uint32_t)k, kb, biased, shift, mask)] + i;
 		if (dst < n) {  // always true for consistent tables; a corrupted table must not turn into a wild store
 			keys_out[dst] = k;
-			vals_out[dst] = sval[i];
+			if constexpr (REC) rec_out[dst] = make_uint4(srec[i].x, srec[i].y, sval[i], 0u);
+			else vals_out[dst] = sval[i];
 		}
 	}
 }
@@ -402,6 +391,29 @@ void gsr_radix_sort_passes(void* k0, uint32_t* v0, void* k1, uint32_t* v1, size_
 		}
 		shift += bits;
 	}
+}
+
+// First level of the bucket depth sort (depthsort.hip): ONE stable pass of the Gaussian-sized kernels on the top-digit bucket
+// of the biased depth keys (gsr_depth_key.h; shift = -1), values = the identity; the elements take their tile rectangles along
+// (rec_in = GsrGeometry::rect, read in index order: coalesced) and arrive as 16-byte records {rectangle, id, 0}.  Uses pass 0's slice of the chunk sums, which
+// must be zero; afterwards [chunk][digit] sums to the bucket sizes.
+void gsr_radix_top_pass(const uint32_t* k0, uint32_t* k1, const uint2* rec_in, uint4* rec_out, size_t n, void* table_mem, const uint32_t* bias, hipStream_t s)
+{
+	if (n == 0) return;
+	uint32_t* chunk_sums = (uint32_t*)table_mem;
+	uint32_t* table = chunk_sums + gsr_radix_clear_words(n);
+	constexpr int ITEMS = GSR_SORT_ITEMS_SMALL;
+	const int nblocks = (int)((n + (size_t)GSR_SORT_THREADS * ITEMS - 1) / ((size_t)GSR_SORT_THREADS * ITEMS));
+	const int nchunks = gsr_radix_top_chunks(n);
+	hipLaunchKernelGGL((gsr_radix_hist_kernel<ITEMS, uint32_t>), dim3(nblocks), dim3(GSR_SORT_THREADS), 0, s, k0, n, -1, 255u, table, nblocks, chunk_sums, nchunks, bias, 1);
+	hipLaunchKernelGGL((gsr_radix_scatter_kernel<ITEMS, uint32_t, true>), dim3(nblocks), dim3(GSR_SORT_THREADS), 0, s, k0, (const uint32_t*)nullptr, k1,
+	                   (uint32_t*)nullptr, n, -1, 8, table, nblocks, chunk_sums, nchunks, bias, rec_in, rec_out);
+}
+// rows of the top pass's [chunk][digit] sums (two levels only: the caller keeps n <= 64 * 64 * 1024)
+int gsr_radix_top_chunks(size_t n)
+{
+	const size_t nblocks_ = (n + (size_t)GSR_SORT_THREADS * GSR_SORT_ITEMS_SMALL - 1) / ((size_t)GSR_SORT_THREADS * GSR_SORT_ITEMS_SMALL);
+	return (int)((nblocks_ + GSR_SORT_CHUNK - 1) / GSR_SORT_CHUNK);
 }
 
 // Sorts on key bits [0, nbits_total).  Ping-pongs between (k0,v0) and (k1,v1); the sorted result

@@ -63,7 +63,8 @@ bool gsr_tilebin_applies(int W, int H) { return gsr_grid_x(W) <= TB_RADIX && gsr
 // [the Gaussians' rectangles and ids in depth order, 16 bytes each: written by pass 1's histogram, read by its scatter]
 size_t gsr_tilebin_col_clear_words(size_t P) { return (tb_chunks(tb_col_blocks(P)) + tb_supers(tb_col_blocks(P))) * TB_RADIX; }
 static inline size_t tb_col_table_words(size_t P) { return gsr_tilebin_col_clear_words(P) + tb_col_blocks(P) * TB_RADIX + TB_RADIX; }
-size_t gsr_tilebin_col_table_bytes(size_t P) { return gsr_align_up(tb_col_table_words(P) * sizeof(uint32_t) + P * sizeof(uint4)); }
+// ... and, behind them, the records {rectangle, id, -} that the bucket depth sort's first level moves along with its keys (depthsort.hip)
+size_t gsr_tilebin_col_table_bytes(size_t P) { return gsr_align_up(tb_col_table_words(P) * sizeof(uint32_t) + 2 * P * sizeof(uint4)); }
 // binning blob: [chunk + super-chunk sums of pass 2, zeroed by pass 1's scatter kernel][block rows]
 size_t gsr_tilebin_row_clear_words(size_t R) { return (tb_chunks(tb_row_blocks_max(R)) + tb_supers(tb_row_blocks_max(R))) * TB_RADIX; }
 size_t gsr_tilebin_row_table_bytes(size_t R)
@@ -204,7 +205,8 @@ __device__ __forceinline__ void tb_expand_group(uint32_t d0, uint32_t len, uint3
 
 // ---- pass 1, histogram: per 1024 depth-ordered Gaussians --------------------------------------------
 // Also leaves the Gaussians' rectangles and ids in depth order (seg: the scatter kernel then starts from one coalesced
-// 16-byte load per Gaussian instead of the chain status word -> permutation -> 8-byte gather) and the workgroup's tile count
+// 16-byte load per Gaussian instead of the chain status word -> permutation -> 8-byte gather; perm == NULL: the bucket depth
+// sort has written seg already, and this kernel starts from that coalesced load too) and the workgroup's tile count
 // (the scatter kernel takes the prefix sums for the gradient-slot numbering), and records where the depth sort left its
 // result.  Runs in forward stage 1, behind the depth sort, while the host waits for the count.
 __global__ void __launch_bounds__(TB_THREADS) gsr_tb_col_hist_kernel(const uint32_t* __restrict__ perm, const uint2* __restrict__ rect, int P,
@@ -225,20 +227,30 @@ __global__ void __launch_bounds__(TB_THREADS) gsr_tb_col_hist_kernel(const uint3
 		if (threadIdx.x < 4) diff[TB_RADIX + threadIdx.x] = 0;
 		uint32_t id[TB_GROUPS];
 		uint2 rc[TB_GROUPS];
+		if (perm) {
 #pragma unroll
-		for (int q = 0; q < TB_GROUPS; q++) {
-			const int i = block * TB_BLOCK + wave * (64 * TB_GROUPS) + q * 64 + lane;
-			id[q] = i < P ? perm[i] : 0xFFFFFFFFu;
+			for (int q = 0; q < TB_GROUPS; q++) {
+				const int i = block * TB_BLOCK + wave * (64 * TB_GROUPS) + q * 64 + lane;
+				id[q] = i < P ? perm[i] : 0xFFFFFFFFu;
+			}
+#pragma unroll
+			for (int q = 0; q < TB_GROUPS; q++) rc[q] = id[q] != 0xFFFFFFFFu ? rect[id[q]] : make_uint2(0u, 0u);
+		} else {   // the bucket depth sort (depthsort.hip) left the rectangles in depth order already: one coalesced load
+#pragma unroll
+			for (int q = 0; q < TB_GROUPS; q++) {
+				const int i = block * TB_BLOCK + wave * (64 * TB_GROUPS) + q * 64 + lane;
+				const uint4 sg = i < P ? seg[i] : make_uint4(0u, 0u, 0xFFFFFFFFu, 0u);
+				rc[q] = make_uint2(sg.x, sg.y);
+				id[q] = sg.z;
+			}
 		}
-#pragma unroll
-		for (int q = 0; q < TB_GROUPS; q++) rc[q] = id[q] != 0xFFFFFFFFu ? rect[id[q]] : make_uint2(0u, 0u);
 		__syncthreads();
 		uint32_t tiles = 0;
 #pragma unroll
 		for (int q = 0; q < TB_GROUPS; q++) {
 			const int i = block * TB_BLOCK + wave * (64 * TB_GROUPS) + q * 64 + lane;
 			const uint32_t w = rc[q].y & 0xffffu, h = rc[q].y >> 16;
-			if (i < P) seg[i] = make_uint4(rc[q].x, rc[q].y, id[q], 0u);
+			if (perm && i < P) seg[i] = make_uint4(rc[q].x, rc[q].y, id[q], 0u);
 			if (w * h) {
 				const uint32_t x0 = rc[q].x & 0xffffu;
 				atomicAdd(&diff[x0], 1);
@@ -522,12 +534,18 @@ static TbColTable tb_col_table(void* mem, int P)
 	return t;
 }
 
-void gsr_launch_tilebin_col_hist(GsrGeometry g, int P, int result_in_alt, hipStream_t s)
+// where pass 1 keeps the Gaussians' rectangles and ids in depth order (the bucket depth sort writes them itself)
+uint4* gsr_tilebin_seg(GsrGeometry g, int P) { return tb_col_table(g.col_table, P).seg; }
+uint4* gsr_tilebin_recs(GsrGeometry g, int P) { return tb_col_table(g.col_table, P).seg + (size_t)P; }
+
+// seg_ready: the depth sort left `seg` (and its order in (depth_keys, perm): result_in_alt = 0)
+void gsr_launch_tilebin_col_hist(GsrGeometry g, int P, int result_in_alt, hipStream_t s, bool seg_ready)
 {
 	const TbColTable t = tb_col_table(g.col_table, P);
 	int per = 1;   // consecutive blocks per workgroup: 1 up to 2 048 blocks, then as many as keep >= 1 024 workgroups
 	while (per < GSR_SORT_CHUNK && t.nblocks / (2 * per) >= 1024) per *= 2;
-	hipLaunchKernelGGL(gsr_tb_col_hist_kernel, dim3((t.nblocks + per - 1) / per), dim3(TB_THREADS), 0, s, result_in_alt ? g.perm_alt : g.perm, g.rect, P,
+	const uint32_t* perm = seg_ready ? nullptr : (result_in_alt ? g.perm_alt : g.perm);
+	hipLaunchKernelGGL(gsr_tb_col_hist_kernel, dim3((t.nblocks + per - 1) / per), dim3(TB_THREADS), 0, s, perm, g.rect, P,
 	                   g.sorted_block_sums, t.table, t.nblocks, t.chunk_sums, t.nchunks, t.seg, g.status, (uint32_t)result_in_alt, per);
 }
 

@@ -59,7 +59,7 @@ class BackwardArgs(ctypes.Structure):
 
 # bits of the C ABI's `debug` mask (include/gsr.h GSR_DEBUG_*).  The reference's bool `debug` is DEBUG_SYNC; tests pass the
 # diagnostic bits as an int in the same argument, per call -- nothing is read from the environment.
-DEBUG_SYNC, DEBUG_NO_CULL, DEBUG_SERIAL, DEBUG_NO_SPLIT, DEBUG_TILE_SORT = 1, 2, 4, 8, 16
+DEBUG_SYNC, DEBUG_NO_CULL, DEBUG_SERIAL, DEBUG_NO_SPLIT, DEBUG_TILE_SORT, DEBUG_RADIX_DEPTH = 1, 2, 4, 8, 16, 32
 
 
 def _dbg(debug):

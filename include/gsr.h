@@ -48,6 +48,8 @@ typedef enum {
 #define GSR_DEBUG_TILE_SORT 16 /* gsr_forward_preprocess* AND gsr_forward_render (pass it to both or to neither): instances are emitted
                                  with their tile ids and radix-sorted (the path of images beyond 256 x 256 tiles) instead of being
                                  binned by column pairs; same point_list, same ranges */
+#define GSR_DEBUG_RADIX_DEPTH 32 /* gsr_forward_preprocess*: the Gaussians are put in depth order by three or four global radix passes (the path
+                                  of more than 2 Mi Gaussians) instead of top-digit buckets sorted inside LDS; same order */
 #define GSR_DEBUG_NO_SPLIT 8 /* gsr_forward_render: heavy tiles (instance lists >= 1024 and >= 2x the mean) are blended by one wave like
                                 every other tile, not by four waves of one 16x4-pixel band each (same results either way) */
 
