@@ -21,10 +21,10 @@
 #ifndef GSR_COLOR_BESIDE_LDS
 #define GSR_COLOR_BESIDE_LDS (40 * 1024)
 #endif
+// (Measured and not kept, round 4: the colour kernel in two pieces -- 40 / 55 / 70 % of its workgroups beside the geometry kernel, the
+// rest held back by an event until the bucket depth sort's last kernel had finished, i.e. beside the binning kernels instead of the
+// sort's round trips -- step 1.092 -> 1.107-1.110 ms at C3: the held-back piece ends after the binning does and the join waits for it.)
 #define GSR_COLOR_BESIDE_MAX_P 1500000
-#ifndef GSR_COLOR_SPLIT_PCT
-#define GSR_COLOR_SPLIT_PCT 55
-#endif
 
 // ---- errors ------------------------------------------------------------------------------------
 static thread_local char g_err[512] = "";
@@ -56,7 +56,7 @@ int gsr_stage_done(hipStream_t s, int debug, const char* stage)
 }
 
 extern "C" const char* gsr_last_error(void) { return g_err; }
-extern "C" const char* gsr_version(void) { return "gsr-hip gfx950 r3"; }
+extern "C" const char* gsr_version(void) { return "gsr-hip gfx950 r4"; }
 
 // ---- per-kernel event profiling ----------------------------------------------------------------
 // One recorder per stream that asked for it (gsr_profile_begin(stream)).  A stage looks its stream up; with no
@@ -346,7 +346,7 @@ static bool aligned16(const void* p) { return ((uintptr_t)p & 15u) == 0; }
 // done with the library returns them with gsr_thread_release().
 struct GsrThreadDevice {
 	hipStream_t aux_stream = nullptr;
-	hipEvent_t aux_fork = nullptr, aux_join = nullptr, aux_mid = nullptr;
+	hipEvent_t aux_fork = nullptr, aux_join = nullptr;
 	uint32_t* status_host = nullptr;
 	hipEvent_t status_event = nullptr;
 	hipStream_t copy_stream = nullptr;   // the count's read-back travels beside the depth sort, not in front of it
@@ -366,7 +366,6 @@ extern "C" int gsr_thread_release(void)
 		if (t.aux_stream) { (void)hipStreamSynchronize(t.aux_stream); if (hipStreamDestroy(t.aux_stream) != hipSuccess) rc = GSR_ERR_HIP; }
 		if (t.aux_fork && hipEventDestroy(t.aux_fork) != hipSuccess) rc = GSR_ERR_HIP;
 		if (t.aux_join && hipEventDestroy(t.aux_join) != hipSuccess) rc = GSR_ERR_HIP;
-		if (t.aux_mid && hipEventDestroy(t.aux_mid) != hipSuccess) rc = GSR_ERR_HIP;
 		if (t.status_event && hipEventDestroy(t.status_event) != hipSuccess) rc = GSR_ERR_HIP;
 		if (t.copy_stream) { (void)hipStreamSynchronize(t.copy_stream); if (hipStreamDestroy(t.copy_stream) != hipSuccess) rc = GSR_ERR_HIP; }
 		if (t.copy_fork && hipEventDestroy(t.copy_fork) != hipSuccess) rc = GSR_ERR_HIP;
@@ -397,6 +396,21 @@ struct GsrJoinOnExit {
 		if (ev && hipStreamWaitEvent(s, ev, 0) != hipSuccess) (void)hipEventSynchronize(ev);
 	}
 };
+
+// Drains the count's read-back stream when the scope ends, unless the host has already waited for the copy: the blit reads
+// geometry->status, and include/gsr.h promises that nothing of it outlives the call -- on the error returns too.
+struct GsrDrainOnExit {
+	hipStream_t st = nullptr;
+	void arm(hipStream_t s) { st = s; }
+	void disarm() { st = nullptr; }
+	~GsrDrainOnExit() { if (st) (void)hipStreamSynchronize(st); }
+};
+
+// What stage 1 last chose on this host thread (binning by column pairs or by the tile sort), and for which geometry buffer: stage 2
+// re-derives the choice from its own `debug` argument, and a caller that passes GSR_DEBUG_TILE_SORT to one call only would otherwise
+// get a point_list built from tables that were never filled.
+struct GsrLastStage1 { const void* geometry = nullptr; bool col_pairs = false; };
+static thread_local GsrLastStage1 g_last_stage1;
 
 // ---- forward, stage 1 --------------------------------------------------------------------------
 static int gsr_forward_preprocess_impl(int P, int D, int M, int width, int height, const float* means3D,
@@ -462,19 +476,18 @@ static int gsr_forward_preprocess_impl(int P, int D, int M, int width, int heigh
 	bool beside = color && !(debug & (GSR_DEBUG_SYNC | GSR_DEBUG_SERIAL)) && !gsr_prof_records_all(s);
 	if (beside && !td.aux_stream) {
 		hipStream_t st = nullptr;
-		hipEvent_t f = nullptr, j = nullptr, m = nullptr;
+		hipEvent_t f = nullptr, j = nullptr;
 		// (Measured and not kept, round 3: a lowest-priority helper stream changes nothing -- the depth sort's first histogram
 		// and scatter still take 15 + 25 us beside the colour kernel instead of 6 + 13 alone; a helper stream confined to every
 		// other CU with hipExtStreamCreateWithCUMask made the step 0.16 ms slower.)
 		if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&f, hipEventDisableTiming) == hipSuccess &&
-		    hipEventCreateWithFlags(&j, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&m, hipEventDisableTiming) == hipSuccess) {
-			td.aux_stream = st; td.aux_fork = f; td.aux_join = j; td.aux_mid = m;
+		    hipEventCreateWithFlags(&j, hipEventDisableTiming) == hipSuccess) {
+			td.aux_stream = st; td.aux_fork = f; td.aux_join = j;
 		} else {
 			(void)hipGetLastError();
 			if (st) (void)hipStreamDestroy(st);
 			if (f) (void)hipEventDestroy(f);
 			if (j) (void)hipEventDestroy(j);
-			if (m) (void)hipEventDestroy(m);
 			beside = false;  // no helper stream: the colour kernel runs in line
 		}
 	}
@@ -485,18 +498,9 @@ static int gsr_forward_preprocess_impl(int P, int D, int M, int width, int heigh
 	// The status words start at zero (a one-workgroup kernel); its dispatch packet signals the helper stream's fork event, so the
 	// helper stream starts where the caller's stream stands now (its inputs are ready there) without a barrier packet of its own
 	gsr_launch_zero_status(a.g.status, s, beside ? td.aux_fork : nullptr);
-	// ... in two pieces when the bucket depth sort follows: its three launches are chains of dependent round trips to L2 / HBM, and
-	// beside the colour kernel's streams every round trip takes twice as long (measured at C3: 11 + 28 + 47 us beside it, 6 + 16 +
-	// 31 alone).  The first GSR_COLOR_SPLIT_PCT percent of the colour workgroups run beside the geometry kernel, the rest is
-	// held back until the depth sort's last kernel has finished (an event its own dispatch packet signals) and runs beside the
-	// binning instead.
-	const int color_blocks = (P + GSR_PREPROCESS_BLOCK - 1) / GSR_PREPROCESS_BLOCK;
-	const bool color_split = beside && bucket && P <= GSR_COLOR_BESIDE_MAX_P && GSR_COLOR_SPLIT_PCT < 100;
-	const int color_first = color_split ? (int)((int64_t)color_blocks * GSR_COLOR_SPLIT_PCT / 100) : color_blocks;
-	const size_t color_throttle = P <= GSR_COLOR_BESIDE_MAX_P ? GSR_COLOR_BESIDE_LDS : 0;
 	if (beside) {
 		if ((rc = gsr_check_hip(hipStreamWaitEvent(td.aux_stream, td.aux_fork, 0), "hipStreamWaitEvent(fork)"))) return rc;
-		gsr_launch_preprocess_color(a, td.aux_stream, color_throttle, 0, color_first);
+		gsr_launch_preprocess_color(a, td.aux_stream, P <= GSR_COLOR_BESIDE_MAX_P ? GSR_COLOR_BESIDE_LDS : 0);
 		if (hipEventRecord(td.aux_join, td.aux_stream) != hipSuccess) {
 			(void)hipStreamSynchronize(td.aux_stream);  // no event to wait for: wait on the host instead, then report
 			return gsr_fail(GSR_ERR_HIP, "hipEventRecord(join) failed");
@@ -545,14 +549,10 @@ static int gsr_forward_preprocess_impl(int P, int D, int M, int width, int heigh
 	hipEvent_t ev = td.status_event;
 	if (copy_beside && (rc = gsr_check_hip(hipStreamWaitEvent(td.copy_stream, td.copy_fork, 0), "hipStreamWaitEvent(copy fork)"))) return rc;
 	hipStream_t cs = copy_beside ? td.copy_stream : s;
-	if ((rc = gsr_check_hip(hipMemcpyAsync(status_host, a.g.status, GSR_STATUS_WORDS * 4, hipMemcpyDeviceToHost, cs), "hipMemcpyAsync(num_rendered)"))) {
-		if (copy_beside) (void)hipStreamSynchronize(td.copy_stream);
-		return rc;
-	}
-	if ((rc = gsr_check_hip(hipEventRecord(ev, cs), "hipEventRecord"))) {
-		if (copy_beside) (void)hipStreamSynchronize(td.copy_stream);   // the copy must not outlive the call
-		return rc;
-	}
+	GsrDrainOnExit drain;   // from here to the host's wait below every return drains the copy's stream: the copy must not outlive the call
+	if (copy_beside) drain.arm(td.copy_stream);
+	if ((rc = gsr_check_hip(hipMemcpyAsync(status_host, a.g.status, GSR_STATUS_WORDS * 4, hipMemcpyDeviceToHost, cs), "hipMemcpyAsync(num_rendered)"))) return rc;
+	if ((rc = gsr_check_hip(hipEventRecord(ev, cs), "hipEventRecord"))) return rc;
 	// The depth sort orders key - min (keys = float bits of the view-space depth; min / max: partial maxima in the status
 	// words, reduced by every sort workgroup).  Its first three 8-bit passes are always needed and are enqueued at once;
 	// whether bits 24..31 of max - min are populated is known once the status block has landed on the host.
@@ -560,17 +560,9 @@ static int gsr_forward_preprocess_impl(int P, int D, int M, int width, int heigh
 	{
 		GsrProfScope p(s, "depth_sort");
 		if (bucket) {
-			gsr_launch_depth_bucket_sort(a.g, P, col_pairs ? gsr_tilebin_seg(a.g, P) : nullptr, s, color_split ? td.aux_mid : nullptr);
+			gsr_launch_depth_bucket_sort(a.g, P, col_pairs ? gsr_tilebin_seg(a.g, P) : nullptr, s);
 			if (col_pairs) gsr_launch_tilebin_col_hist(a.g, P, 0, s, true);
 			else gsr_launch_sorted_block_sums(a.g, P, 0, s);
-			if (color_split) {   // the rest of the colour kernel, behind the depth sort; the join event moves behind it
-				if ((rc = gsr_check_hip(hipStreamWaitEvent(td.aux_stream, td.aux_mid, 0), "hipStreamWaitEvent(colour, second piece)"))) return rc;
-				gsr_launch_preprocess_color(a, td.aux_stream, color_throttle, color_first, -1);
-				if ((rc = gsr_check_hip(hipEventRecord(td.aux_join, td.aux_stream), "hipEventRecord(join)"))) {
-					(void)hipStreamSynchronize(td.aux_stream);
-					return rc;
-				}
-			}
 		} else {
 			gsr_radix_sort_passes(a.g.depth_keys, a.g.perm, a.g.depth_keys_alt, a.g.perm_alt, (size_t)P, 32, 4, 0, 3, a.g.sort_table, bias, 4, s);
 			// ... and so are the block sums over the three-pass result (the common case) -- with them, for images the column-pair
@@ -582,6 +574,9 @@ static int gsr_forward_preprocess_impl(int P, int D, int M, int width, int heigh
 	}
 	if ((rc = gsr_stage_done(s, debug, "depth_sort"))) return rc;
 	if ((rc = gsr_check_hip(hipEventSynchronize(ev), "hipEventSynchronize(num_rendered)"))) return rc;
+	drain.disarm();   // (the copy has landed)
+	g_last_stage1.geometry = geometry;
+	g_last_stage1.col_pairs = col_pairs;
 	if (status_host[0] & 1u)  // (the join guard makes `stream` wait for the colour kernel first)
 		return gsr_fail(GSR_ERR_PREFILTERED, "Point is filtered although prefiltered is set. This shouldn't happen!");
 	int64_t total = 0;
@@ -661,6 +656,9 @@ extern "C" int gsr_forward_render(int P, int64_t R, int width, int height, const
 	GsrBinning b;
 	memset(&b, 0, sizeof b);
 	const bool col_pairs = gsr_tilebin_applies(width, height) && !(debug & GSR_DEBUG_TILE_SORT);   // (as stage 1 decided)
+	if (g_last_stage1.geometry == geometry && g_last_stage1.col_pairs != col_pairs)
+		return gsr_fail(GSR_ERR_INVALID_ARGUMENT, "gsr_forward_render: GSR_DEBUG_TILE_SORT must be passed to both forward calls or to neither "
+		                "(gsr_forward_preprocess on this thread prepared this geometry buffer for the other binning)");
 	if (R > 0) b = gsr_binning_view(binning, P, R, width, height);
 	if (R > 0 && col_pairs) {
 		// column pairs by tile column, their instances by tile row (tilebin.hip): point_list, ranges and the cleared validity

@@ -236,7 +236,7 @@ __global__ void __launch_bounds__(256) gsr_tile_ranges_kernel(const KeyT* __rest
 #define GSR_ORDER_PER_THREAD 9  // 9 216 tiles per pass: 1920x1080 (8 160) and 1980x1080 (8 432) in one
 // work estimate of a tile: instances the backward will stage (tile_max_contrib given) or the length of its range (the
 // forward's upper bound, before anything is known about where its pixels saturate)
-__device__ __forceinline__ uint32_t gsr_tile_work(const uint2* __restrict__ ranges, const uint32_t* __restrict__ tile_max_contrib, uint32_t t)
+__device__ __forceinline__ uint32_t gsr_tile_work(const uint2* ranges, const uint32_t* tile_max_contrib, uint32_t t)
 {
 #ifdef GSR_TILE_CLOCK
 	if (!ranges) return tile_max_contrib[t];  // diagnostic twin: a key supplied by the tool
@@ -275,10 +275,12 @@ extern "C" int gsr_debug_backward_key(uint32_t* key) { g_debug_backward_key = ke
 // the mean list and are walked to the end (low opacities), the one wave of the heaviest tile WAS the launch (342 of 342 us,
 // profiles/r3_tile_clock_c3_lowop.txt).  Heavy = range length >= 16 * (GSR_ORDER_BINS - 1 - split_bin_max), the heaviest
 // first, at most max_split tiles; the entries [ntiles + 3 nsplit, ntiles + 3 max_split) are marked empty.
-__global__ void __launch_bounds__(1024) gsr_tile_order_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ tile_max_contrib,
+// (ranges and ranges_fix are the same array when the forward normalises empty tiles: neither may be __restrict__; what is written
+// there -- (0, 0) over (p, p) -- leaves every tile's work at 0, so the later reads through `ranges` see the same work either way)
+__global__ void __launch_bounds__(1024) gsr_tile_order_kernel(const uint2* ranges, const uint32_t* __restrict__ tile_max_contrib,
                                                               uint32_t ntiles, uint32_t* __restrict__ order, int split_bin_max, uint32_t max_split,
-                                                              uint32_t* __restrict__ tile_max_contrib_out, uint32_t seg_budget, int allow_cut,
-                                                              uint2* __restrict__ ranges_fix)
+                                                              uint32_t* tile_max_contrib_out, uint32_t seg_budget, int allow_cut,
+                                                              uint2* ranges_fix)
 {
 	__shared__ uint32_t bin[GSR_ORDER_BINS];
 	__shared__ uint32_t wsum[1024 / 64];

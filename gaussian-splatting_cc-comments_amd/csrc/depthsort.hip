@@ -30,7 +30,6 @@
 // Nothing here depends on the keys being spread out: the histogram levels re-read the bucket once per group of DS_CAP elements,
 // by one workgroup -- correct for any input, fast only for the inputs that occur (tests/test_depth_sort_gpu.py holds the others).
 #include "gsr_internal.h"
-#include <hip/hip_ext.h>
 #include "gsr_depth_key.h"
 
 #define DS_THREADS 256
@@ -574,7 +573,7 @@ bool gsr_bucket_sort_applies(int P) { return P > 0 && P <= GSR_BUCKET_SORT_MAX_P
 
 // Depth order of the P Gaussians into (depth_keys, perm) -- status word 2 = 0 -- and, seg != NULL, their rectangles in that order.
 // The depth sort's table must have its chunk sums at zero (the preprocess kernel clears them).
-void gsr_launch_depth_bucket_sort(GsrGeometry g, int P, uint4* seg, hipStream_t s, hipEvent_t done)
+void gsr_launch_depth_bucket_sort(GsrGeometry g, int P, uint4* seg, hipStream_t s)
 {
 	const uint32_t* bias = g.status + GSR_STATUS_NEGMIN;
 	uint4* recs = gsr_tilebin_recs(g, P);   // level 1's records {tile rectangle, id, -} in bucket order
@@ -582,10 +581,6 @@ void gsr_launch_depth_bucket_sort(GsrGeometry g, int P, uint4* seg, hipStream_t 
 	// what the chip holds at once (three workgroups per CU: LDS), each taking items in turn; fewer when there cannot be that many items
 	const size_t items_max = 2 * ((size_t)P / DS_PART_TARGET) + 256;
 	const unsigned grid = (unsigned)(items_max < 256 * DS_GRID_PER_CU ? items_max : 256 * DS_GRID_PER_CU);
-	if (done)
-		hipExtLaunchKernelGGL(gsr_ds_bucket_kernel, dim3(grid), dim3(DS_THREADS), 0, s, nullptr, done, 0, g.depth_keys_alt, (const uint4*)recs, g.depth_keys, g.perm, seg,
-		                      (uint32_t)P, (const uint32_t*)g.sort_table, gsr_radix_top_chunks((size_t)P), bias);
-	else
-		hipLaunchKernelGGL(gsr_ds_bucket_kernel, dim3(grid), dim3(DS_THREADS), 0, s, g.depth_keys_alt, (const uint4*)recs, g.depth_keys, g.perm, seg, (uint32_t)P,
-		                   (const uint32_t*)g.sort_table, gsr_radix_top_chunks((size_t)P), bias);
+	hipLaunchKernelGGL(gsr_ds_bucket_kernel, dim3(grid), dim3(DS_THREADS), 0, s, g.depth_keys_alt, (const uint4*)recs, g.depth_keys, g.perm, seg, (uint32_t)P,
+	                   (const uint32_t*)g.sort_table, gsr_radix_top_chunks((size_t)P), bias);
 }

@@ -117,7 +117,7 @@ struct GsrPreprocessArgs {
 void gsr_launch_preprocess(const GsrPreprocessArgs& a, hipStream_t s, hipEvent_t done = nullptr);
 void gsr_launch_zero_status(uint32_t* status, hipStream_t s, hipEvent_t done = nullptr);
 bool gsr_preprocess_needs_color(const GsrPreprocessArgs& a);
-void gsr_launch_preprocess_color(const GsrPreprocessArgs& a, hipStream_t s, size_t throttle = 0, int block_first = 0, int block_count = -1);
+void gsr_launch_preprocess_color(const GsrPreprocessArgs& a, hipStream_t s, size_t throttle = 0);
 void gsr_launch_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8_t* present, hipStream_t s);
 
 // binning.hip
@@ -154,7 +154,7 @@ int gsr_radix_top_chunks(size_t n);
 // depthsort.hip: depth order in three launches (top-digit buckets, then every bucket sorted inside LDS) for up to this many Gaussians
 #define GSR_BUCKET_SORT_MAX_P (2 << 20)
 bool gsr_bucket_sort_applies(int P);
-void gsr_launch_depth_bucket_sort(GsrGeometry g, int P, uint4* seg, hipStream_t s, hipEvent_t done = nullptr);   // done: signalled by the last kernel's own dispatch packet
+void gsr_launch_depth_bucket_sort(GsrGeometry g, int P, uint4* seg, hipStream_t s);
 // bytes per tile key of an instance-sized sort: 2 when every tile id fits 16 bits AND the sort runs the instance-sized
 // kernels (sort.hip), else 4
 int gsr_tile_key_bytes(int ntiles, size_t num_rendered);

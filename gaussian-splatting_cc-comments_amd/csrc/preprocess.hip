@@ -173,13 +173,12 @@ __global__ void __launch_bounds__(GSR_PREPROCESS_BLOCK) gsr_preprocess_kernel(Gs
 // again).  Done for every Gaussian in front of the near plane -- a superset of those the geometry kernel keeps (it
 // also drops det == 0 and empty rectangles); what is written for the difference is never read.
 template <bool LEAF>
-__global__ void __launch_bounds__(GSR_PREPROCESS_BLOCK) gsr_preprocess_color_kernel(GsrPreprocessArgs a, int sh_via_lds, int block_first)
+__global__ void __launch_bounds__(GSR_PREPROCESS_BLOCK) gsr_preprocess_color_kernel(GsrPreprocessArgs a, int sh_via_lds)
 {
-	const int block = (int)blockIdx.x + block_first;   // (the kernel may be launched in pieces: api.hip)
 	// staging of the wave's SH block: the packed layout passes through in two halves of 32 rows (6.6 KB per wave, so that
 	// 4 waves per SIMD fit), the split leaf tensors as one linear 12 KB block
 	__shared__ float4 s_sh[GSR_PREPROCESS_BLOCK / 64][(LEAF ? 64 : 32) * GSR_SH_ROW4];
-	const int idx = block * GSR_PREPROCESS_BLOCK + threadIdx.x;
+	const int idx = blockIdx.x * GSR_PREPROCESS_BLOCK + threadIdx.x;
 	GsrVec3 p_orig = {0.f, 0.f, 0.f};
 	if (idx < a.P) { p_orig.x = a.means3D[3 * idx]; p_orig.y = a.means3D[3 * idx + 1]; p_orig.z = a.means3D[3 * idx + 2]; }
 	// The wave's 64 x 48 SH floats are contiguous in HBM: stage them into LDS with coalesced float4
@@ -187,7 +186,7 @@ __global__ void __launch_bounds__(GSR_PREPROCESS_BLOCK) gsr_preprocess_color_ker
 	float row[48];  // the lane's own SH row (registers: only ever indexed with constants)
 	if (sh_via_lds) {
 		const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-		const int wave_first = block * GSR_PREPROCESS_BLOCK + wave * 64;
+		const int wave_first = blockIdx.x * GSR_PREPROCESS_BLOCK + wave * 64;
 		const int nrows = min(64, a.P - wave_first);
 		if (LEAF) {
 			if (nrows > 0) gsr_sh_lin_load(reinterpret_cast<float*>(s_sh[wave]), a.shs, a.shs_rest, wave_first, nrows, lane);
@@ -286,19 +285,16 @@ bool gsr_preprocess_needs_color(const GsrPreprocessArgs& a) { return a.shs && !a
 
 // throttle: bytes of (unused) dynamic LDS per workgroup -- limits how many workgroups of this kernel a CU holds at once when it
 // runs beside the depth sort on the helper stream (api.hip)
-// block_first / block_count: the workgroups (of GSR_PREPROCESS_BLOCK Gaussians) this launch covers; count < 0 = all from block_first on
-void gsr_launch_preprocess_color(const GsrPreprocessArgs& a, hipStream_t s, size_t throttle, int block_first, int block_count)
+void gsr_launch_preprocess_color(const GsrPreprocessArgs& a, hipStream_t s, size_t throttle)
 {
-	const int nb_all = (a.P + GSR_PREPROCESS_BLOCK - 1) / GSR_PREPROCESS_BLOCK;
-	const int nb = block_count < 0 ? nb_all - block_first : block_count;
-	if (nb <= 0) return;
+	const int nb = (a.P + GSR_PREPROCESS_BLOCK - 1) / GSR_PREPROCESS_BLOCK;
 	// LDS-transposed SH path: the flagship layout (16 coefficients), 16-byte aligned tensor
 	int sh_via_lds = (a.M == 16 && ((uintptr_t)a.shs & 15u) == 0) ? 1 : 0;
 	if (a.leaf) {
 		if (((uintptr_t)a.shs_rest & 15u) != 0) sh_via_lds = 0;
-		hipLaunchKernelGGL(gsr_preprocess_color_kernel<true>, dim3(nb), dim3(GSR_PREPROCESS_BLOCK), throttle, s, a, sh_via_lds, block_first);
+		hipLaunchKernelGGL(gsr_preprocess_color_kernel<true>, dim3(nb), dim3(GSR_PREPROCESS_BLOCK), throttle, s, a, sh_via_lds);
 	} else {
-		hipLaunchKernelGGL(gsr_preprocess_color_kernel<false>, dim3(nb), dim3(GSR_PREPROCESS_BLOCK), throttle, s, a, sh_via_lds, block_first);
+		hipLaunchKernelGGL(gsr_preprocess_color_kernel<false>, dim3(nb), dim3(GSR_PREPROCESS_BLOCK), throttle, s, a, sh_via_lds);
 	}
 }
 

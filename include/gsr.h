@@ -78,7 +78,8 @@ size_t gsr_backward_scratch_bytes(int P, int64_t num_rendered);
 typedef struct {
 	size_t splat;          /* [P] 48-byte records: xy(2f) conic a b c + opacity(4f) rect_min(u16x2) rect_wh(u16x2) rgb(3f) unused(u32) */
 	size_t depth_keys;     /* [P] u32: after the call, depth bits sorted ascending (culled = 0xFFFFFFFF last) -- in this array or in */
-	size_t depth_keys_alt; /* [P] u32 its ping-pong partner: status word 2 says which (1 = the _alt pair; three radix passes sufficed) */
+	size_t depth_keys_alt; /* [P] u32 its ping-pong partner: status word 2 says which (0 always after the bucket sort of up to 2 Mi Gaussians;
+	                          with the global radix passes 1 = the _alt pair: three passes sufficed) */
 	size_t perm;           /* [P] u32 Gaussian ids in (depth, id) order (or in perm_alt, see above) */
 	size_t perm_alt;       /* [P] u32 sort ping-pong */
 	size_t tiles_touched;  /* [P] u32 */
@@ -91,7 +92,8 @@ typedef struct {
 	                          counts; 68..131 / 132..195: partial maxima of ~depth key / depth key of the visible Gaussians) */
 	size_t scan_temp;      /* per-workgroup tile counts in depth order */
 	size_t sort_table;     /* radix histogram table of the depth sort */
-	size_t col_table;      /* column-pair binning, pass 1 (by tile column): chunk sums, per-workgroup digit rows, 256 digit totals */
+	size_t col_table;      /* column-pair binning, pass 1 (by tile column): chunk sums, per-workgroup digit rows, 256 digit totals, the
+	                          Gaussians' {rectangle, id} records in depth order and (bucket depth sort) in bucket order, 16 B each */
 	size_t total;
 } gsr_geometry_layout;
 
@@ -116,8 +118,9 @@ typedef struct {
 	size_t total;
 	size_t tile_key_bytes; /* 2 (uint16_t: every tile id of the image is below 65 536) or 4 (uint32_t); both arrays are sized for 4 */
 	size_t column_pairs;   /* 1: images of at most 256 x 256 tiles are binned by column pairs (no per-instance tile keys exist: the tile
-	                          of sorted instance i follows from `ranges`; tile_keys then holds the sorted column pairs, u16 y0 | h - 1 << 8,
-	                          point_list_alt their Gaussian ids) unless GSR_DEBUG_TILE_SORT is passed; 0: always the tile sort */
+	                          of sorted instance i follows from `ranges`; [point_list_alt, tile_keys_alt) then holds up to R interleaved
+	                          8-byte records {u32 y0 | (h - 1) << 8, u32 Gaussian id}, sorted by tile column, then depth) unless
+	                          GSR_DEBUG_TILE_SORT is passed; 0: always the tile sort */
 } gsr_binning_layout;
 
 int gsr_geometry_layout_of(int P, gsr_geometry_layout* out);

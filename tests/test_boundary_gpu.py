@@ -470,3 +470,37 @@ def test_bench_view_parallel_path_over_rccl_one_rank():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["value"] > 0 and "view-parallel" in d["config"]["parallelism"]
     assert d["alt_exchange"]["mode"] == "allreduce" and d["alt_exchange"]["value"] > 0
+
+
+def test_stage2_refuses_a_binning_choice_stage1_did_not_make():
+    """GSR_DEBUG_TILE_SORT selects the instance emission + tile sort in BOTH forward calls; stage 2 re-derives the choice from its own
+    debug argument.  Passed to one call only, stage 2 would bin from tables stage 1 never filled: it must refuse instead
+    (GSR_ERR_INVALID_ARGUMENT), both ways round, and the matching pairs must still run."""
+    _need_gpu()
+    from diff_gaussian_rasterization import _C
+    L = _C.lib()
+    dev = torch.device("cuda:0")
+    scene = gsr_scene.make_scene(3000, -3.0, sh_degree=1, seed=5)
+    cam = gsr_scene.make_camera(160, 96)
+    st = util.hip_settings(scene, cam, 1, dev)
+    t = {k: getattr(scene, k).to(dev).contiguous() for k in ("means3D", "shs", "opacities", "scales", "rotations")}
+    P, W, H = 3000, 160, 96
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    p = lambda x: ctypes.c_void_p(x.data_ptr())
+    for d1, d2, ok in ((0, 0, True), (_C.DEBUG_TILE_SORT, _C.DEBUG_TILE_SORT, True), (_C.DEBUG_TILE_SORT, 0, False), (0, _C.DEBUG_TILE_SORT, False)):
+        geom = torch.empty(L.gsr_geometry_bytes(P), dtype=torch.uint8, device=dev)
+        img = torch.empty(L.gsr_image_bytes(W, H), dtype=torch.uint8, device=dev)
+        radii = torch.empty(P, dtype=torch.int32, device=dev)
+        out = torch.empty(3, H, W, device=dev)
+        R = ctypes.c_int64(0)
+        rc = L.gsr_forward_preprocess(P, 1, 4, W, H, p(t["means3D"]), p(t["shs"]), None, p(t["opacities"]), p(t["scales"]), 1.0, p(t["rotations"]),
+                                      None, p(st.viewmatrix), p(st.projmatrix), p(st.campos), float(st.tanfovx), float(st.tanfovy), 0, p(radii),
+                                      p(geom), ctypes.byref(R), stream, d1)
+        assert rc == 0, L.gsr_last_error()
+        binning = torch.empty(L.gsr_binning_bytes(P, R.value, W, H), dtype=torch.uint8, device=dev)
+        rc = L.gsr_forward_render(P, R.value, W, H, p(st.bg), p(radii), p(geom), p(binning), p(img), p(out), stream, d2)
+        torch.cuda.synchronize()
+        if ok:
+            assert rc == 0, L.gsr_last_error()
+        else:
+            assert rc == -1 and b"GSR_DEBUG_TILE_SORT" in L.gsr_last_error()
