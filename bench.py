@@ -31,12 +31,13 @@ import gsr_scene  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, corrected as
 # MI355X_MICROARCH.md "HBM" prescribes) of this same command, summarised by tools/pmc_summary.py
-PMC_SUMMARY = next((f for f in (os.path.join(ROOT, "profiles", n) for n in ("r3b_pmc_summary.json", "r3_pmc_summary.json", "r2_pmc_summary.json", "r1_pmc_summary.json"))
+PMC_SUMMARY = next((f for f in (os.path.join(ROOT, "profiles", n) for n in ("r4_pmc_summary.json", "r3b_pmc_summary.json", "r3_pmc_summary.json", "r2_pmc_summary.json", "r1_pmc_summary.json"))
                     if os.path.exists(f)), os.path.join(ROOT, "profiles", "r3_pmc_summary.json"))
 KERNEL_SYMBOL = {"render_backward": "gsr_render_backward_wave_kernel", "render_forward": "gsr_render_forward_wave_kernel",
                  "gaussian_backward": "gsr_gaussian_backward_kernel", "preprocess": "gsr_preprocess_kernel",
                  "preprocess_color": "gsr_preprocess_color_kernel",
-                 "duplicate_keys": "gsr_duplicate_keys_kernel", "tile_ranges": "gsr_tile_ranges_kernel"}
+                 "duplicate_keys": "gsr_duplicate_keys_kernel", "tile_ranges": "gsr_tile_ranges_kernel",
+                 "col_scatter": "gsr_tb_col_scatter_kernel", "row_hist": "gsr_tb_row_hist_kernel", "row_scatter": "gsr_tb_row_scatter_kernel"}
 
 
 DOMINANT_STAGE = "render_backward"   # the kernel with the largest launch time in every configuration measured
@@ -70,16 +71,26 @@ def algorithmic_bytes(P, V, R, Rp, N, T, M):
         "duplicate_keys": 20 * P + 12 * R,
         "sort": 24 * R,
         "tile_ranges": 8 * R + 16 * T,
-        # the column-pair binning (csrc/tilebin.hip) replaces the three stages above as a whole: "binning" = its three
-        # kernels together, priced at the SURVEY's bytes for the stages they replace
-        "binning": (20 * P + 12 * R) + 24 * R + (8 * R + 16 * T),
+        # What the binning chain of this library REPLACES, priced at the SURVEY's bytes for the reference's stages: InclusiveSum +
+        # duplicateWithKeys + SortPairs (all 64 key bits: the depth sort does the depth half) + identifyTileRanges
+        # (rasterizer_impl.cu:323, 78-159, 357-385) = 28 P + 44 R + 16 T.  A comparison figure ("vs replaced stages"), not the
+        # bytes these kernels move: see binning_moved_bytes()
+        "binning_chain": 8 * P + (20 * P + 12 * R) + 24 * R + (8 * R + 16 * T),
         "render_forward": 8 * T + 40 * Rp + 20 * N,
     }
     bwd = {
         "render_backward": 8 * T + 40 * R + 20 * N + 44 * V,
-        "gaussian_backward": 92 * V + (sh + 339) * V + 300 * P,
+        "gaussian_backward": 92 * V + (sh + 339) * V + 300 * P,   # includes re-reading the SH row, which this kernel does not do
     }
     return fwd, bwd
+
+
+def binning_moved_bytes(P, V, R, T, pairs):
+    """Bytes the column-pair binning's three stage-2 kernels have to move by their own design (csrc/tilebin.hip): pass 1's scatter
+    reads the 16-byte depth-ordered records of all P Gaussians and writes one 8-byte column pair per (Gaussian, tile column) and the
+    visible Gaussians' slot bases; pass 2 reads the pairs twice (histogram, scatter) and writes 4 bytes per instance (point_list),
+    the validity byte per instance and 8 bytes per tile (ranges).  No per-instance key exists."""
+    return dict(col_scatter=16 * P + 8 * pairs + 4 * V, row_hist=8 * pairs, row_scatter=8 * pairs + 5 * R + 8 * T)
 
 
 def host_cores():
@@ -297,6 +308,9 @@ def parse_args():
                     help="diagnostics only: bits of the C ABI's `debug` mask (include/gsr.h GSR_DEBUG_*) passed with every call, e.g. 32 = "
                          "global radix passes for the depth order, 16 = instance emission + tile sort: A/B of the alternate paths on "
                          "one box.  Reported in config; the headline line is the run with 0")
+    ap.add_argument("--library", default=None,
+                    help="diagnostics only: path of another build of the C ABI (csrc/Makefile `variant`) to bind instead of the product "
+                         "library, for A/B runs on one box.  Reported in config; the headline line is the run without it")
     ap.add_argument("--dry-run", action="store_true",
                     help="rehearsal of the N > 1 plumbing WITHOUT the rasterizer (no GPU needed): ranks are spawned, the "
                          "process group is formed and every step runs only the gradient exchange on synthetic buffers")
@@ -463,6 +477,8 @@ def run_rank(args, rank, world, dev, phase=None, grouped=None):
         settings = None
     else:
         from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer, _C
+        if args.library:
+            _C.use_library(args.library)
         _C.lib()  # fail loudly if the HIP library is missing
         scene = gsr_scene.make_scene(P, mu, D, seed=0)          # replicated parameters
         # views of this rank: BASELINE.json configs[3] puts 8 cameras on a ring; rank r renders views r, r + world, ...
@@ -633,7 +649,7 @@ def run_rank(args, rank, world, dev, phase=None, grouped=None):
 
     def spy(*a):
         r = orig(*a)
-        cap["R"], cap["img"] = r[0], r[5]
+        cap["R"], cap["img"], cap["geom"] = r[0], r[5], r[3]
         return r
     _C.rasterize_gaussians = spy
     with torch.no_grad():
@@ -658,15 +674,47 @@ def run_rank(args, rank, world, dev, phase=None, grouped=None):
         kern[name] = dict(ms=round(avg, 4), launches=len(v), algorithmic_bytes=allb.get(name),
                           GBps=round(allb[name] / (avg * 1e-3) / 1e9, 1) if allb.get(name) and avg > 0 else None,
                           hbm_frac=round(allb[name] / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 3) if allb.get(name) and avg > 0 else None)
-    tb = [kern[n]["ms"] for n in ("col_scatter", "row_hist", "row_scatter") if n in kern]
+    # every kernel also against the bytes the PMC counters saw it move (profiles/, same workload): a kernel that moves less than the
+    # reference's stage would (or more) is then read against what it does, not against what it replaces
+    for name, e in kern.items():
+        tr = pmc_traffic(name, args.config) if name in KERNEL_SYMBOL else None
+        if tr and e["ms"] > 0:
+            e.update(pmc_traffic_bytes=int(tr), traffic_GBps=round(tr / (e["ms"] * 1e-3) / 1e9, 1), traffic_frac=round(tr / (e["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 3))
+    if "gaussian_backward" in kern:
+        kern["gaussian_backward"]["note"] = ("algorithmic_bytes / hbm_frac are SURVEY 8(d)'s, which re-read the 192-byte SH row per visible Gaussian; this "
+                                             "kernel reads the 36 bytes of colour derivatives the forward left instead, so it is to be read against what it "
+                                             "moves: pmc_traffic_bytes / traffic_frac")
+    tb = [n for n in ("col_scatter", "row_hist", "row_scatter") if n in kern]
     if len(tb) == 3:
-        ms = sum(tb)
-        kern["binning"] = dict(ms=round(ms, 4), launches=None, algorithmic_bytes=allb["binning"], GBps=round(allb["binning"] / (ms * 1e-3) / 1e9, 1),
-                               hbm_frac=round(allb["binning"] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 3),
-                               note="col_scatter + row_hist + row_scatter = duplicateWithKeys + SortPairs (tile bits) + identifyTileRanges of the "
-                                    "reference, against SURVEY 8(d)'s algorithmic bytes of those three stages")
-    step_bytes = sum(v for k, v in fwd_b.items() if k != "binning") + sum(bwd_b.values())
-    dom = max((k for k in kern if k != "binning"), key=lambda k: kern[k]["ms"]) if kern else None
+        # column pairs of this view = sum over the visible Gaussians of their rectangles' widths (the geometry buffer's dense rectangles)
+        gl = _C.geometry_layout(P)
+        rect = cap["geom"][gl.rect:gl.rect + 8 * P].view(torch.int32).view(P, 2)[:, 1]
+        wdt, hgt = rect & 0xFFFF, (rect >> 16) & 0xFFFF
+        pairs = int(wdt[(wdt * hgt) > 0].sum().item())
+        moved = binning_moved_bytes(P, V, R, T, pairs)
+        for n in tb:
+            kern[n].update(algorithmic_bytes=moved[n], GBps=round(moved[n] / (kern[n]["ms"] * 1e-3) / 1e9, 1),
+                           hbm_frac=round(moved[n] / (kern[n]["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 3))
+        ms = sum(kern[n]["ms"] for n in tb)
+        mb = sum(moved.values())
+        kern["binning"] = dict(ms=round(ms, 4), launches=None, column_pairs=pairs, algorithmic_bytes=mb, GBps=round(mb / (ms * 1e-3) / 1e9, 1),
+                               hbm_frac=round(mb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 3),
+                               note="col_scatter + row_hist + row_scatter of the column-pair binning against the bytes THEY have to move "
+                                    "(16 P + 4 V + 24 B per column pair + 5 R + 8 T: no per-instance key exists); these kernels are bound by "
+                                    "their LDS instruction stream and dependent round trips, not by bytes")
+        if "depth_sort" in kern:
+            cms = ms + kern["depth_sort"]["ms"]
+            cb = allb["binning_chain"]
+            kern["binning_chain"] = dict(ms=round(cms, 4), launches=None, vs_replaced_stages_bytes=cb,
+                                         vs_replaced_stages_GBps=round(cb / (cms * 1e-3) / 1e9, 1),
+                                         vs_replaced_stages_frac=round(cb / (cms * 1e-3) / 1e9 / HBM_PEAK_GBS, 3),
+                                         note="depth_sort (depth order of the Gaussians + pass 1's histogram) + col_scatter + row_hist + row_scatter = "
+                                              "everything that replaces InclusiveSum + duplicateWithKeys + SortPairs + identifyTileRanges of the reference, "
+                                              "against SURVEY 8(d)'s bytes for THOSE stages (28 P + 44 R + 16 T): a comparison with what the reference's "
+                                              "stages would need at HBM speed, not this chain's own traffic; kernel times of the serial per-kernel table "
+                                              "(in the timed region the depth sort shares the chip with the colour kernel)")
+    step_bytes = sum(v for k, v in fwd_b.items() if k != "binning_chain") + sum(bwd_b.values())
+    dom = max((k for k in kern if k not in ("binning", "binning_chain")), key=lambda k: kern[k]["ms"]) if kern else None
     roofline = None
     if dom:
         if dom == DOMINANT_STAGE and dom_times:   # its launches inside the timed region
@@ -674,12 +722,13 @@ def run_rank(args, rank, world, dev, phase=None, grouped=None):
             kern[dom].update(ms=round(avg, 4), launches=len(dom_times), measured_in="timed region",
                              GBps=round(allb[dom] / (avg * 1e-3) / 1e9, 1) if allb.get(dom) and avg > 0 else None)
         a = kern[dom]["GBps"] or 0.0
-        roofline = dict(kernel=dom, bound="hbm", achieved=a, peak=HBM_PEAK_GBS, unit="GB/s",
+        roofline = dict(kernel=dom, bound="valu_issue", achieved=a, peak=HBM_PEAK_GBS, unit="GB/s",
                         frac=round(a / HBM_PEAK_GBS, 4), traffic=pmc_traffic(dom, args.config),
                         valu_issue=valu_issue_fraction(dom, args.config, kern[dom]["ms"]),
-                        note="this kernel is bound by vector-ALU issue, not by HBM (see valu_issue: its instructions priced per class at "
-                             "the rates this chip sustains, against its duration), so its HBM fraction is small by construction; "
-                             "'kernels' lists the streaming stages with their own HBM fractions",
+                        note="achieved / peak / frac are the HBM figures the contract asks for (algorithmic bytes per launch over the launch's "
+                             "duration against 8 TB/s); the roof that BINDS this kernel is vector-ALU issue (bound = valu_issue; valu_issue.frac: its "
+                             "instructions, counted by the SQ counters, over the rate this chip sustains on a stream of the same class mix, against "
+                             "its duration), so its HBM fraction is small by construction; 'kernels' lists the streaming stages with their own HBM fractions",
                         avg_launch_ms=kern[dom]["ms"], algorithmic_bytes_per_launch=kern[dom]["algorithmic_bytes"],
                         step_algorithmic_bytes=step_bytes,
                         step_GBps=round(step_bytes / (ms_per_step * 1e-3) / 1e9, 1),
@@ -694,6 +743,8 @@ def run_rank(args, rank, world, dev, phase=None, grouped=None):
                             "kernels add up to more than the step")
     if args.debug_mask:
         out["config"]["debug_mask"] = args.debug_mask   # a diagnostic run of an alternate path, not the headline
+    if args.library:
+        out["config"]["library"] = os.path.basename(args.library)   # a diagnostic run of an A/B build, not the headline
     if world == 1 and not args.no_extras:
         out["loss_l1_ssim"] = bench_loss(state["color"].detach(), dev)
         if not args.no_train_step:

@@ -267,6 +267,9 @@ __device__ __forceinline__ uint32_t gsr_tile_segments(uint32_t work, uint32_t co
 // durations it measured in the previous step), to bound what a better work estimate could be worth
 static uint32_t* g_debug_backward_key = nullptr;
 extern "C" int gsr_debug_backward_key(uint32_t* key) { g_debug_backward_key = key; return 0; }
+// ... and the forward (tools/tile_clock.py --forward-key: e.g. the work the previous forward of the same view counted per tile)
+static uint32_t* g_debug_forward_key = nullptr;
+extern "C" int gsr_debug_forward_key(uint32_t* key) { g_debug_forward_key = key; return 0; }
 #endif
 
 // Forward only (split_bin_max >= 0): HEAVY tiles are handed out as four entries, one per 16x4-pixel band (entry = tile |
@@ -408,6 +411,7 @@ void gsr_launch_tile_order(GsrImage img, int ntiles, bool backward, int64_t num_
 	const uint2* ranges = img.ranges;
 #ifdef GSR_TILE_CLOCK
 	if (backward && g_debug_backward_key) { key = g_debug_backward_key; ranges = nullptr; }
+	if (!backward && g_debug_forward_key) { key = g_debug_forward_key; ranges = nullptr; split = false; }
 #endif
 	// heavy (forward only): a list of at least 1024 instances that is also at least twice the mean list (how deep a list is
 	// walked is not known before the forward has run; on the low-opacity blob scene the tiles that set the span were walked

@@ -72,6 +72,7 @@ __global__ void __launch_bounds__(64 * GSR_WAVES_PER_WG) __attribute__((amdgpu_w
 		last[k] = 0u;
 	}
 
+	GSR_TILE_STAT(unsigned long long st_staged = 0ull; unsigned long long st_bands = 0ull; unsigned long long st_hits = 0ull;)   // (diagnostic twin: wave-uniform work counters)
 	// software pipeline: records one batch ahead, ids two batches ahead
 	float4 ra = make_float4(0, 0, 0, 0), rb = ra, rc = ra;
 	if (lane < n) {
@@ -95,6 +96,7 @@ __global__ void __launch_bounds__(64 * GSR_WAVES_PER_WG) __attribute__((amdgpu_w
 		const bool keep = bands != 0u;
 		const unsigned long long mask = __builtin_amdgcn_ballot_w64(keep);
 		const int cnt = __popcll(mask);
+		GSR_TILE_STAT(st_staged += (unsigned long long)cnt;)
 		if (keep) {
 			const int pos = gsr_mbcnt(mask);
 			rec[0][pos] = make_float4(ra.x, ra.y, -0.5f * ra.z, ra.w);  // conic a, c pre-multiplied by -0.5 (exact)
@@ -138,6 +140,7 @@ __global__ void __launch_bounds__(64 * GSR_WAVES_PER_WG) __attribute__((amdgpu_w
 				// the three comparisons are SGPR lane masks; what follows them is scalar arithmetic
 				const unsigned long long live = __builtin_amdgcn_ballot_w64(!(power > 0.0f)) & __builtin_amdgcn_ballot_w64(!(alpha < 1.0f / 255.0f));
 				const unsigned long long passm = live & alive[k] & __builtin_amdgcn_ballot_w64(!(test_T < 0.0001f));
+				GSR_TILE_STAT(st_bands++; st_hits += passm ? 1ull : 0ull;)
 				alive[k] = (alive[k] & ~live) | passm;  // a live instance either passes or ends the pixel
 				const bool pass = __builtin_amdgcn_inverse_ballot_w64(passm);
 				const float w = pass ? alpha * Tout[k] : 0.0f;
@@ -175,7 +178,10 @@ __global__ void __launch_bounds__(64 * GSR_WAVES_PER_WG) __attribute__((amdgpu_w
 		if (only) atomicMax(&tile_max_contrib[tile], m);  // zeroed by the order kernel for the tiles it split
 		else tile_max_contrib[tile] = m;
 	}
-	GSR_TILE_CLOCK_STOP(gsr_forward_tile_clock, slot_id, lane, (unsigned long long)entry, 0ull);   // one record per dispatch entry
+	// one record per dispatch entry; work counters: instances staged after the band cull (20 bits), bands evaluated (22), bands in which
+	// at least one pixel blended the instance (22)
+	GSR_TILE_CLOCK_STOP(gsr_forward_tile_clock, slot_id, lane, (unsigned long long)entry,
+	                    (st_staged & 0xFFFFFull) | ((st_bands & 0x3FFFFFull) << 20) | ((st_hits & 0x3FFFFFull) << 42));
 }
 
 void gsr_launch_render_forward(int W, int H, GsrImage img, const uint32_t* point_list, const GsrSplat* splat, float4* checkpoints,

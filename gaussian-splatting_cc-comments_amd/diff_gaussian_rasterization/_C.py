@@ -15,8 +15,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# GSR_HIP_LIBRARY: another build of the same C ABI (e.g. the diagnostic build of tools/tile_clock.py)
-_LIB_PATH = os.environ.get("GSR_HIP_LIBRARY") or os.path.join(os.path.dirname(_HERE), "libgsr_hip.so")
+_LIB_PATH = os.path.join(os.path.dirname(_HERE), "libgsr_hip.so")   # nothing in the environment changes this: see use_library()
 _lib = None
 
 _vp = ctypes.c_void_p
@@ -68,6 +67,16 @@ def _dbg(debug):
 
 def library_path():
     return _LIB_PATH
+
+
+def use_library(path):
+    """Diagnostics (tools/tile_clock.py, bench.py --library): bind another build of the same C ABI -- the per-tile-clock twin, an
+    A/B variant of one translation unit -- instead of the product library.  Must be called before the first lib(); the product
+    never calls it."""
+    global _LIB_PATH
+    if _lib is not None:
+        raise RuntimeError("use_library() must be called before the library is first loaded")
+    _LIB_PATH = os.path.abspath(path)
 
 
 def lib():

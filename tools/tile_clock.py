@@ -21,7 +21,6 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, "gaussian-splatting_cc-comments_amd")
 TWIN = os.path.join(PKG, "libgsr_hip_tileclock.so")
-os.environ["GSR_HIP_LIBRARY"] = TWIN
 sys.path.insert(0, PKG)
 sys.path.insert(0, ROOT)
 
@@ -29,7 +28,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 
-def analyse(name, rec, waves_per_simd, out):
+def analyse(name, rec, waves_per_simd, out, forward=False):
     rec = rec.astype(np.int64)
     rec = rec[rec[:, 1] > 0]
     t0, t1 = rec[:, 0], rec[:, 1]
@@ -59,7 +58,21 @@ def analyse(name, rec, waves_per_simd, out):
     if rec.shape[1] >= 6:   # shader clock over the waves' own lifetimes (s_memtime ticks per 100 MHz tick)
         ghz = float((rec[:, 5] - rec[:, 4]).sum()) / float((t1 - t0).sum()) * 0.1
         print(f"   shader clock while the waves ran: {ghz:.3f} GHz (s_memtime / s_memrealtime over all waves)", file=out)
-    if rec.shape[1] >= 8 and rec[:, 6].any():
+    if forward and rec.shape[1] >= 8 and rec[:, 7].any():   # the forward's record: dispatch entry, then its work counters
+        sb = rec[:, 7]
+        staged, bands, hits = int((sb & 0xFFFFF).sum()), int(((sb >> 20) & 0x3FFFFF).sum()), int(((sb >> 42) & 0x3FFFFF).sum())
+        whole = (rec[:, 6] >> 28) == 0
+        print(f"   work: {staged} instances staged after the band cull ({staged / max(len(rec), 1):.0f} per wave), {bands} bands of 16x4 pixels evaluated "
+              f"({bands / max(staged, 1):.2f} per staged instance), {hits} of them with at least one pixel blending the instance ({hits / max(bands, 1):.2f}); "
+              f"{int(whole.sum())} whole-tile waves, {int((~whole).sum())} one-band waves", file=out)
+        # what a wave's duration is made of: least squares of the duration on (1, staged, bands)
+        A = np.stack([np.ones(len(rec)), (sb & 0xFFFFF).astype(float), ((sb >> 20) & 0x3FFFFF).astype(float)], axis=1)
+        d_us = (t1 - t0) * 0.01
+        coef, *_ = np.linalg.lstsq(A, d_us, rcond=None)
+        pred = A @ coef
+        print(f"   duration ~ {coef[0]:.1f} us + {coef[1] * 1e3:.1f} ns per staged instance + {coef[2] * 1e3:.1f} ns per evaluated band  "
+              f"(R^2 {1 - ((d_us - pred) ** 2).sum() / ((d_us - d_us.mean()) ** 2).sum():.2f}: the rest is who shared the SIMD)", file=out)
+    elif rec.shape[1] >= 8 and rec[:, 6].any():
         sa, sb = rec[:, 6], rec[:, 7]
         staged, pairs, pairs_hit = int((sa & 0xFFFFF).sum()), int(((sa >> 20) & 0x3FFFFF).sum()), int(((sa >> 42) & 0x3FFFFF).sum())
         red, lanes = int((sb & 0xFFFFFF).sum()), int((sb >> 24).sum())
@@ -96,12 +109,14 @@ def main():
     ap.add_argument("--dump", default=None, help="npz with the raw clocks and the dispatch keys")
     ap.add_argument("--scene", default="uniform", choices=["uniform", "blob", "lowop"],
                     help="uniform: the benchmark scene of --config; blob / lowop: the non-uniform 1M-Gaussian scenes of tools/skew_bench.py")
+    ap.add_argument("--forward-key", action="store_true", help="also dispatch the forward by the work / durations just measured")
     ap.add_argument("--measured-key", action="store_true", help="also dispatch the backward by its own measured durations")
     a = ap.parse_args()
     if not os.path.exists(TWIN):
         raise SystemExit(f"{TWIN} missing: make -C gaussian-splatting_cc-comments_amd/csrc tile_clock")
     import gsr_scene
     from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer, _C
+    _C.use_library(TWIN)   # the diagnostic twin instead of the product library
     L = _C.lib()
     dev = torch.device("cuda:0")
     P, W, H, D, mu = gsr_scene.CONFIGS[a.config]
@@ -156,7 +171,7 @@ def main():
         getattr(L, f"gsr_debug_tile_clock_{k}")(None)
     out = open(a.out, "w") if a.out else sys.stdout
     print(f"# tools/tile_clock.py --config {a.config} --scene {a.scene}: P={P} {W}x{H}, {ntiles} tiles, one wave64 per tile; clocks on the 100 MHz constant clock", file=out)
-    analyse("render_forward (6 waves per SIMD, 80 VGPRs)", bufs["forward"].cpu().numpy(), 6, out)
+    analyse("render_forward (6 waves per SIMD, 80 VGPRs)", bufs["forward"].cpu().numpy(), 6, out, forward=True)
     analyse("render_backward (4 waves per SIMD, 128 VGPRs)", bufs["backward"].cpu().numpy(), 4, out)
     # how well does the dispatch key predict a tile's duration?
     il = _C.image_layout(W, H)
@@ -179,9 +194,36 @@ def main():
     fd, bd = (f[:, 1] - f[:, 0]) * 0.01, (b[:, 1] - b[:, 0]) * 0.01
     rank = lambda x: np.argsort(np.argsort(x))
     rc = lambda x, y: float(np.corrcoef(rank(x), rank(y))[0, 1])
+    fwork = ((f[:, 7] >> 20) & 0x3FFFFF).astype(np.int64)   # bands evaluated by the tile's wave
+    print(f"== forward: rank correlation of a wave's duration with its evaluated bands {rc(fwork, fd):.2f}, with its staged instances "
+          f"{rc((f[:, 7] & 0xFFFFF).astype(np.int64), fd):.2f}; of the evaluated bands with the range length {rc(fwork, length):.2f}, with the largest n_contrib {rc(fwork, tmc):.2f}", file=out)
     print(f"== dispatch keys: rank correlation with the wave's duration: forward, range length {rc(length, fd):.2f}; "
           f"backward, staged instances {rc(staged, bd):.2f}; forward duration vs backward duration {rc(fd, bd):.2f}; "
           f"largest n_contrib vs forward duration {rc(tmc, fd):.2f}", file=out)
+    if a.forward_key:
+        # Would a better dispatch key shorten the forward?  Dispatch it by what the forward just counted per tile -- the bands it
+        # evaluated, i.e. its real work, which no key known BEFORE the forward predicts (range length: see above) but which the
+        # previous forward of the same view would -- and by its measured durations, and compare the launch spans.
+        L.gsr_debug_forward_key.argtypes = [ctypes.c_void_p]
+        span = lambda rec: (rec[:, 1].max() - rec[:, 0].min()) * 0.01
+        print(f"== forward dispatched by keys only a previous forward of the same view can supply: span with the product key (range length) {span(f):.1f} us", file=out)
+        for label, keyv in (("bands evaluated", fwork), ("largest n_contrib", tmc), ("measured duration", ((f[:, 1] - f[:, 0]) // 4))):
+            key = torch.from_numpy(np.asarray(keyv).astype(np.int32)).to(dev)
+            assert L.gsr_debug_forward_key(key.data_ptr()) == 0
+            spans = []
+            for rep in range(3):
+                for _ in range(2):
+                    step()
+                torch.cuda.synchronize()
+                fnf = L.gsr_debug_tile_clock_forward
+                assert fnf(bufs["forward"].data_ptr()) == 0
+                step()
+                torch.cuda.synchronize()
+                fnf(None)
+                rec = bufs["forward"].cpu().numpy()[:ntiles]
+                spans.append(span(rec))
+            print(f"   by {label}: span {' / '.join(f'{x:.1f}' for x in spans)} us", file=out)
+        L.gsr_debug_forward_key(None)
     if a.measured_key:
         # Is a better dispatch key to be had?  Dispatch the backward by the durations just measured (three rounds: the durations
         # change with the order) and compare the launch spans.  (Measured at C3: 543 us with the product key, 629 / 594 / 592
