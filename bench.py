@@ -203,13 +203,19 @@ def bench_loss(image, dev, iters=20):
     fused()
     kt = dict(_C.profile_end())
     n = image.numel()
+    # bytes per kernel: forward reads x, y and writes the three maps the backward needs; backward reads the maps, x, y and writes the gradient
+    kb = dict(ssim_forward=n * 4 * (2 + 3), ssim_backward=n * 4 * (3 + 2 + 1))
+    kern = {k: dict(ms=round(v, 4), algorithmic_bytes=int(kb[k]), GBps=round(kb[k] / (v * 1e-3) / 1e9, 1), hbm_frac=round(kb[k] / (v * 1e-3) / 1e9 / HBM_PEAK_GBS, 3))
+            for k, v in kt.items() if k in kb and v > 0}
     return dict(fused_ms=round(t_fused, 4), stock_pytorch_ms=round(t_stock, 4),
-                kernels_ms={k: round(v, 4) for k, v in kt.items()},
+                kernels_ms={k: round(v, 4) for k, v in kt.items()}, kernels=kern,
                 algorithmic_bytes=int(n * 4 * (2 + 3 + 3 + 2 + 1)),  # A: read x,y write 3 maps; B: read 3 maps, x, y, write grad
+                bound="LDS / vector ALU, not HBM: per output pixel and map the separable 11-tap window costs 22 multiply-adds out of LDS-staged "
+                      "tiles with an 11-pixel halo (csrc/loss.hip); profiles/r4_pmc_summary_extras.json holds the kernels' counters",
                 note="fwd+bwd of loss = 0.8*L1 + 0.2*(1-SSIM) on the rendered (3,H,W) image; not included in `value`")
 
 
-def bench_train_step(scene, settings, D, dev, iters=10):
+def bench_train_step(scene, settings, D, dev, iters=10, modes=("stock_around", "fused_loss", "all_fused")):
     """Whole training iteration (render -> L1+SSIM loss -> backward -> Adam step, train.py:93-131,179-181) three
     ways on the benchmark scene; an extra next to the headline metric, not part of `value`:
       stock_around : PyTorch activations, stock-PyTorch loss and torch.optim.Adam around the HIP rasterizer
@@ -268,11 +274,106 @@ def bench_train_step(scene, settings, D, dev, iters=10):
         for _ in range(iters):
             it()
         torch.cuda.synchronize()
-        return round((time.perf_counter() - t0) / iters * 1e3, 4)
+        ms = round((time.perf_counter() - t0) / iters * 1e3, 4)
+        if mode == "all_fused":
+            # what the iteration is made of: every library stage of one more iteration, timed in line (HIP events around each stage --
+            # the colour kernel then runs in line too, so the stages add up to MORE than the iteration, in which it overlaps)
+            from diff_gaussian_rasterization import _C
+            _C.profile_begin()
+            it()
+            torch.cuda.synchronize()
+            kt = {}
+            for name, t in _C.profile_end():
+                kt[name] = kt.get(name, 0.0) + t
+            nfloat = sum(p.numel() for g in opt.param_groups for p in g["params"])
+            adam_bytes = 28 * nfloat   # per float: parameter, gradient, two moments read (16 B), parameter and moments written (12 B)
+            extra["all_fused_stages_ms"] = {k: round(v, 4) for k, v in kt.items()}
+            extra["all_fused_stages_sum_ms"] = round(sum(kt.values()), 4)
+            if kt.get("adam", 0) > 0:
+                extra["adam"] = dict(ms=round(kt["adam"], 4), floats=nfloat, algorithmic_bytes=adam_bytes, GBps=round(adam_bytes / (kt["adam"] * 1e-3) / 1e9, 1),
+                                     hbm_frac=round(adam_bytes / (kt["adam"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 3), bound="hbm",
+                                     note="one launch over the six parameter groups (59 floats per Gaussian), 28 B per float: the streaming minimum")
+        return ms
 
-    res = {m: run(m) for m in ("stock_around", "fused_loss", "all_fused")}
-    return dict(ms_per_iteration=res, note="render + 0.8*L1+0.2*(1-SSIM) + backward + Adam(6 groups, eps 1e-15) + zero_grad; "
-                                          "parameters move, so V and R drift slightly from the headline workload")
+    extra = {}
+    res = {m: run(m) for m in modes}
+    return dict(ms_per_iteration=res, **extra,
+                note="render + 0.8*L1+0.2*(1-SSIM) + backward + Adam(6 groups, eps 1e-15) + zero_grad; parameters move, so V and R drift "
+                     "slightly from the headline workload.  all_fused_stages_ms: the library's stages of one all_fused iteration timed in line "
+                     "(their sum exceeds the iteration by what overlaps in it: the colour kernel); what the iteration holds beyond them is the "
+                     "caller's PyTorch work (zeros_like, zero_grad, the allocator) and launch gaps -- profiles/r4_train_iteration_timeline.txt")
+
+
+def bench_views_in_flight(scene, D, W, H, dev, iters=20, nviews=2):
+    """Not part of `value`: two views of the ring (BASELINE.json configs[3]'s cameras) per step on ONE GPU, rendered one after the
+    other and two in flight on two streams (view_parallel.ViewsInFlight) -- the per-rank mode of view-parallel training with
+    gradient accumulation.  Same work, same gradients (checked here bit for bit); what changes is what the chip does during a
+    view's latency-bound binning chain and the blend kernels' tails."""
+    import view_parallel
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    to = lambda t: t.to(dev)
+    params = dict(means3D=to(scene.means3D).requires_grad_(True), shs=to(scene.shs).requires_grad_(True),
+                  opacities=to(scene.opacities).requires_grad_(True), scales=to(scene.scales).requires_grad_(True),
+                  rotations=to(scene.rotations).requires_grad_(True))
+    cams = [gsr_scene.ring_camera(W, H, k=v, n=8) for v in range(nviews)]
+    rasts = [GaussianRasterizer(GaussianRasterizationSettings(
+        image_height=H, image_width=W, tanfovx=c.tanfovx, tanfovy=c.tanfovy, bg=to(scene.bg), scale_modifier=1.0, viewmatrix=to(c.world_view_transform),
+        projmatrix=to(c.full_proj_transform), sh_degree=D, campos=to(c.camera_center), prefiltered=False, debug=False)) for c in cams]
+    dpixs = [to(torch.randn(3, H, W, generator=torch.Generator().manual_seed(11 + v))) for v in range(nviews)]
+
+    def fn(r):
+        def f():
+            m2 = torch.zeros_like(params["means3D"], requires_grad=True)
+            return r(means3D=params["means3D"], means2D=m2, **{k: v for k, v in params.items() if k != "means3D"})[0]
+        return f
+    fns = [fn(r) for r in rasts]
+    vif = view_parallel.ViewsInFlight(dev, 2)
+    vif_st = view_parallel.ViewsInFlight(dev, 2, staggered=True)
+
+    def staggered():
+        for p in params.values():
+            p.grad = None
+        vif_st.forward_backward(fns, dpixs)
+
+    def sequential():
+        for p in params.values():
+            p.grad = None
+        for f, dp in zip(fns, dpixs):
+            f().backward(dp)
+
+    def interleaved():
+        for p in params.values():
+            p.grad = None
+        vif.forward_backward(fns, dpixs)
+
+    def timeit(step):
+        for _ in range(5):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            step()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / iters * 1e3
+    sequential()
+    torch.cuda.synchronize()
+    ref = {k: p.grad.clone() for k, p in params.items()}
+    interleaved()
+    torch.cuda.synchronize()
+    same = all(torch.equal(ref[k], p.grad) for k, p in params.items())
+    t_seq, t_int = timeit(sequential), timeit(interleaved)
+    t_seq2, t_int2 = timeit(sequential), timeit(interleaved)
+    t_seq, t_int = min(t_seq, t_seq2), min(t_int, t_int2)
+    staggered()
+    torch.cuda.synchronize()
+    same = same and all(torch.equal(ref[k], p.grad) for k, p in params.items())
+    t_stag = min(timeit(staggered), timeit(staggered))
+    return dict(views_per_step=nviews, sequential_ms_per_step=round(t_seq, 4), in_flight_ms_per_step=round(t_int, 4), staggered_ms_per_step=round(t_stag, 4),
+                sequential_views_per_s=round(nviews / t_seq * 1e3, 1), in_flight_views_per_s=round(nviews / t_int * 1e3, 1),
+                speedup=round(t_seq / t_int, 4), gradients_bit_identical=bool(same),
+                note="two ring views per step on one GPU, gradients accumulated: one view after the other vs two in flight on two streams "
+                     "(view_parallel.ViewsInFlight; bench.py --views-per-rank 2 --views-in-flight 2 is the same as a timed region); an extra, "
+                     "not the headline")
 
 
 def parse_args():
@@ -295,6 +396,13 @@ def parse_args():
                          "59 floats/Gaussian through view_parallel.GradientBucket).  Default 1 = BASELINE.json configs[3] (one view "
                          "per rank and step, exchange pipelined with the per-Gaussian backward); k > 1 shows the amortised case: "
                          "value counts views, so it stays comparable")
+    ap.add_argument("--views-in-flight", type=int, default=1,
+                    help="with --views-per-rank k >= 2: forward + backward of this many consecutive views at a time on as many streams "
+                         "(view_parallel.ViewsInFlight): a view's depth sort / binning runs under the other view's blend kernels.  "
+                         "Gradients are bit for bit those of the sequential loop.  Default 1 = one view after the other")
+    ap.add_argument("--staggered", action="store_true",
+                    help="with --views-in-flight: every view's forward and backward are issued before the next view's forward, views "
+                         "alternating over the streams (view_parallel.ViewsInFlight(staggered=True))")
     ap.add_argument("--collective-timeout-s", type=float, default=180.0,
                     help="N > 1: timeout of the process group (init and every collective); a rank that waits longer exits non-zero "
                          "with a message and the launcher stops its siblings")
@@ -508,10 +616,26 @@ def run_rank(args, rank, world, dev, phase=None, grouped=None):
             if (grouped and kviews == 1) else {}
         bucket = view_parallel.GradientBucket(list(params.values())) if (grouped and kviews > 1) else None
 
+        vif = view_parallel.ViewsInFlight(dev, args.views_in_flight, staggered=args.staggered) if (args.views_in_flight > 1 and kviews > 1 and not (grouped and kviews == 1)) else None
+
+        def render_fn(rast):
+            def f():
+                means2D = torch.zeros_like(params["means3D"], requires_grad=True)
+                color, radii = rast(means3D=params["means3D"], means2D=means2D, **{k: v for k, v in params.items() if k != "means3D"})
+                state["radii"] = radii
+                return color
+            return f
+        render_fns = [render_fn(r) for r in rasterizers]
+
         def make_step(mode):
             def step():
                 for p in params.values():
                     p.grad = None
+                if vif is not None:   # k local views, several in flight (their gradients accumulate into .grad in view order)
+                    state["color"] = vif.forward_backward(render_fns, dpixs)[-1]
+                    if bucket is not None:
+                        bucket.all_reduce()
+                    return
                 for rast, st, dp in zip(rasterizers, all_settings, dpixs):
                     means2D = torch.zeros_like(params["means3D"], requires_grad=True)  # gaussian_renderer/__init__.py:37
                     if grouped and kviews == 1:
@@ -631,6 +755,9 @@ def run_rank(args, rank, world, dev, phase=None, grouped=None):
     else:
         parallelism = "single view" if kviews == 1 else f"{kviews} views per step, gradients accumulated"
     if kviews > 1:
+        out["views_in_flight"] = args.views_in_flight if (args.views_in_flight > 1) else 1
+        if args.views_in_flight > 1 and args.staggered:
+            out["views_in_flight_schedule"] = "staggered"
         out["views_per_rank"] = kviews
         out["value_note"] = "value = views (fwd+bwd rasterize iterations) per second over all ranks; one step = views_per_rank views per rank"
     if args.dry_run:
@@ -746,6 +873,7 @@ def run_rank(args, rank, world, dev, phase=None, grouped=None):
     if args.library:
         out["config"]["library"] = os.path.basename(args.library)   # a diagnostic run of an A/B build, not the headline
     if world == 1 and not args.no_extras:
+        out["two_views_in_flight"] = bench_views_in_flight(scene, D, W, H, dev)
         out["loss_l1_ssim"] = bench_loss(state["color"].detach(), dev)
         if not args.no_train_step:
             for p in params.values():

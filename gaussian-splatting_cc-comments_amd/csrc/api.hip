@@ -13,13 +13,15 @@
 #include "gsr_internal.h"
 
 #define GSR_MAX_DEVICES 64
-// Beside the depth sort the SH colour kernel is held to two workgroups per CU (40 KB of unused dynamic LDS each): it has until the
-// end of the depth sort to finish, and at full occupancy its memory traffic doubled the latency-bound first launches of that sort
-// (histogram 6 -> 15 us, scatter 13 -> 25).  Measured at C3: step 1.167 -> 1.160 ms with two workgroups per CU (three: 1.161, one:
-// 1.161).  Only while the colour kernel is the shorter of the two: its time grows with P, the depth sort's barely (C5, 6M
-// Gaussians: colour 0.42 ms against 0.25 ms of sort -- there it keeps the whole chip).
-#ifndef GSR_COLOR_BESIDE_LDS
-#define GSR_COLOR_BESIDE_LDS (40 * 1024)
+// Beside the depth sort the SH colour kernel is held to two workgroups per CU (unused dynamic LDS on top of its staging area): it has
+// until the end of the depth sort to finish, and at full occupancy its memory traffic doubled the latency-bound first launches of
+// that sort (histogram 6 -> 15 us, scatter 13 -> 25).  Measured at C3: step 1.167 -> 1.160 ms with two workgroups per CU (three:
+// 1.161, one: 1.161).  Only while the colour kernel is the shorter of the two: its time grows with P, the depth sort's barely (C5,
+// 6M Gaussians: colour 0.42 ms against 0.25 ms of sort -- there it keeps the whole chip).  (Round 4: the limit used to be a fixed
+// 40 KB of dynamic LDS, which on top of the LEAF kernel's 52 KB left ONE workgroup per CU -- 0.224 ms instead of 0.06, and the
+// training iteration's binning waited 110 us for it: profiles/r4_train_iteration_timeline_before.txt.)
+#ifndef GSR_COLOR_BESIDE_WGS
+#define GSR_COLOR_BESIDE_WGS 2
 #endif
 // (Measured and not kept, round 4: the colour kernel in two pieces -- 40 / 55 / 70 % of its workgroups beside the geometry kernel, the
 // rest held back by an event until the bucket depth sort's last kernel had finished, i.e. beside the binning kernels instead of the
@@ -500,7 +502,7 @@ static int gsr_forward_preprocess_impl(int P, int D, int M, int width, int heigh
 	gsr_launch_zero_status(a.g.status, s, beside ? td.aux_fork : nullptr);
 	if (beside) {
 		if ((rc = gsr_check_hip(hipStreamWaitEvent(td.aux_stream, td.aux_fork, 0), "hipStreamWaitEvent(fork)"))) return rc;
-		gsr_launch_preprocess_color(a, td.aux_stream, P <= GSR_COLOR_BESIDE_MAX_P ? GSR_COLOR_BESIDE_LDS : 0);
+		gsr_launch_preprocess_color(a, td.aux_stream, P <= GSR_COLOR_BESIDE_MAX_P ? GSR_COLOR_BESIDE_WGS : 0);
 		if (hipEventRecord(td.aux_join, td.aux_stream) != hipSuccess) {
 			(void)hipStreamSynchronize(td.aux_stream);  // no event to wait for: wait on the host instead, then report
 			return gsr_fail(GSR_ERR_HIP, "hipEventRecord(join) failed");

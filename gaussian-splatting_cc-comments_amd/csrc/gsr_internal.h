@@ -117,7 +117,7 @@ struct GsrPreprocessArgs {
 void gsr_launch_preprocess(const GsrPreprocessArgs& a, hipStream_t s, hipEvent_t done = nullptr);
 void gsr_launch_zero_status(uint32_t* status, hipStream_t s, hipEvent_t done = nullptr);
 bool gsr_preprocess_needs_color(const GsrPreprocessArgs& a);
-void gsr_launch_preprocess_color(const GsrPreprocessArgs& a, hipStream_t s, size_t throttle = 0);
+void gsr_launch_preprocess_color(const GsrPreprocessArgs& a, hipStream_t s, int wgs_per_cu = 0);
 void gsr_launch_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8_t* present, hipStream_t s);
 
 // binning.hip

@@ -283,13 +283,16 @@ void gsr_launch_preprocess(const GsrPreprocessArgs& a, hipStream_t s, hipEvent_t
 // the colour kernel exists only for SH colours
 bool gsr_preprocess_needs_color(const GsrPreprocessArgs& a) { return a.shs && !a.colors_precomp; }
 
-// throttle: bytes of (unused) dynamic LDS per workgroup -- limits how many workgroups of this kernel a CU holds at once when it
-// runs beside the depth sort on the helper stream (api.hip)
-void gsr_launch_preprocess_color(const GsrPreprocessArgs& a, hipStream_t s, size_t throttle)
+// wgs_per_cu: 0 = as many workgroups per CU as fit; else the kernel is held to that many by (unused) dynamic LDS on top of its own
+// staging area (26 KB, 52 KB in leaf mode) -- while it runs beside the depth sort on the helper stream (api.hip)
+void gsr_launch_preprocess_color(const GsrPreprocessArgs& a, hipStream_t s, int wgs_per_cu)
 {
 	const int nb = (a.P + GSR_PREPROCESS_BLOCK - 1) / GSR_PREPROCESS_BLOCK;
 	// LDS-transposed SH path: the flagship layout (16 coefficients), 16-byte aligned tensor
 	int sh_via_lds = (a.M == 16 && ((uintptr_t)a.shs & 15u) == 0) ? 1 : 0;
+	const size_t own = (size_t)(GSR_PREPROCESS_BLOCK / 64) * (a.leaf ? 64 : 32) * GSR_SH_ROW4 * sizeof(float4);
+	const size_t share = wgs_per_cu > 0 ? (size_t)160 * 1024 / (size_t)wgs_per_cu : 0;
+	const size_t throttle = share > own + 1024 ? share - own - 1024 : 0;   // (1 KB of slack for allocation granularity)
 	if (a.leaf) {
 		if (((uintptr_t)a.shs_rest & 15u) != 0) sh_via_lds = 0;
 		hipLaunchKernelGGL(gsr_preprocess_color_kernel<true>, dim3(nb), dim3(GSR_PREPROCESS_BLOCK), throttle, s, a, sh_via_lds);

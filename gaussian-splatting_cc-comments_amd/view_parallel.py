@@ -330,3 +330,67 @@ class DensificationStats:
         """after densify_and_prune (gaussian_model.py:396-398 zeroes the accumulators)"""
         for t in (self.max_radii2D, self.xyz_gradient_accum, self.denom, self._local_sum, self._local_max):
             t.zero_()
+
+
+class ViewsInFlight:
+    """Several of a rank's views in flight on one GPU: forward + backward of `in_flight` consecutive views on as many streams.
+
+    One view leaves the chip mostly idle for a fifth of its time -- the depth sort and the binning between the per-Gaussian kernel
+    and the forward blend are chains of short, latency-bound launches -- and the two blend kernels end in tails of half-empty
+    SIMDs.  The rasterizer keeps no state between calls and enqueues everything on the caller's stream, so a second view on
+    another stream fills both: its stage 1 and binning run under the first view's blend kernels.  Views are independent until
+    their gradients are added (train.py:105-119 renders one view per step), and PyTorch's autograd adds them into
+    the parameters' .grad in the order of the backward calls -- the order of the sequential loop -- so the accumulated gradients
+    are bit for bit those of rendering the views one after the other (tests/test_boundary_gpu.py).
+
+        vif = ViewsInFlight(device, in_flight=2)
+        vif.forward_backward(render_fns, upstream_grads)      # render_fns[v]() -> image of view v (calls the rasterizer)
+    """
+
+    def __init__(self, device, in_flight: int = 2, staggered: bool = False):
+        if in_flight < 1:
+            raise ValueError("in_flight must be at least 1")
+        self.device = torch.device(device)
+        self.streams = [torch.cuda.Stream(self.device) for _ in range(in_flight)]
+        # staggered: every view's forward AND backward are issued before the next view's forward, views alternating over the
+        # streams -- a view's stage 1 and binning then run under the previous view's backward blend and its forward blend under
+        # the previous view's per-Gaussian backward, instead of like phases of `in_flight` views running side by side
+        self.staggered = staggered
+
+    def forward_backward(self, render_fns, upstream_grads):
+        """Forward and backward of every view, `in_flight` at a time; returns the images (detached).  Work issued before the call on
+        the current stream is waited for by the side streams, and the current stream waits for them at the end."""
+        cur = torch.cuda.current_stream(self.device)
+        n = len(self.streams)
+        images = []
+        if self.staggered:
+            for st in self.streams:
+                st.wait_stream(cur)
+            for v, f in enumerate(render_fns):
+                st = self.streams[v % n]
+                g = upstream_grads[v]
+                g.record_stream(st)
+                with torch.cuda.stream(st):
+                    img = f()
+                    img.backward(g)
+                images.append(img.detach())
+            for st in self.streams:
+                cur.wait_stream(st)
+            return images
+        for first in range(0, len(render_fns), n):
+            group = list(range(first, min(first + n, len(render_fns))))
+            live = []
+            for v, st in zip(group, self.streams):
+                st.wait_stream(cur)
+                with torch.cuda.stream(st):
+                    live.append(render_fns[v]())
+            # the backward calls in view order: autograd adds a view's gradients into .grad when its backward runs
+            for v, st, img in zip(group, self.streams, live):
+                g = upstream_grads[v]
+                g.record_stream(st)
+                with torch.cuda.stream(st):
+                    img.backward(g)
+                images.append(img.detach())
+            for st in self.streams[:len(group)]:
+                cur.wait_stream(st)
+        return images

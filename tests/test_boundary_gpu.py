@@ -504,3 +504,43 @@ def test_stage2_refuses_a_binning_choice_stage1_did_not_make():
             assert rc == 0, L.gsr_last_error()
         else:
             assert rc == -1 and b"GSR_DEBUG_TILE_SORT" in L.gsr_last_error()
+
+
+def test_two_views_in_flight_accumulate_the_sequential_gradients_bit_for_bit():
+    """view_parallel.ViewsInFlight: forward + backward of two views at a time on two streams.  The library keeps no state between
+    calls and works on the caller's stream; autograd adds the views' gradients in the order of the backward calls: images and
+    accumulated gradients must be exactly those of rendering the views one after the other (three views: a full pair and a rest)."""
+    _need_gpu()
+    import view_parallel
+    from diff_gaussian_rasterization import GaussianRasterizer
+    dev = torch.device("cuda:0")
+    scene = gsr_scene.make_scene(60_000, -4.0, sh_degree=3, seed=12)
+    W, H = 640, 360
+    cams = [gsr_scene.ring_camera(W, H, k, 8) for k in (0, 3, 5)]
+    names = ("means3D", "shs", "opacities", "scales", "rotations")
+    params = {k: getattr(scene, k).to(dev).requires_grad_(True) for k in names}
+    rasts = [GaussianRasterizer(util.hip_settings(scene, c, 3, dev)) for c in cams]
+    dpixs = [torch.randn(3, H, W, generator=torch.Generator().manual_seed(20 + k)).to(dev) for k in range(3)]
+
+    def fn(r):
+        def f():
+            m2 = torch.zeros_like(params["means3D"], requires_grad=True)
+            return r(means3D=params["means3D"], means2D=m2, **{k: v for k, v in params.items() if k != "means3D"})[0]
+        return f
+    fns = [fn(r) for r in rasts]
+    images_seq = []
+    for f, dp in zip(fns, dpixs):
+        img = f()
+        img.backward(dp)
+        images_seq.append(img.detach().clone())
+    torch.cuda.synchronize()
+    ref = {k: p.grad.clone() for k, p in params.items()}
+    for trial in range(3):
+        for p in params.values():
+            p.grad = None
+        images = view_parallel.ViewsInFlight(dev, 2).forward_backward(fns, dpixs)
+        torch.cuda.synchronize()
+        for a, b in zip(images, images_seq):
+            assert torch.equal(a, b)
+        for k, p in params.items():
+            assert torch.equal(p.grad, ref[k]), k

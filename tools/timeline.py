@@ -10,19 +10,22 @@ import csv
 import statistics
 import sys
 
-path = sys.argv[1]
-last = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+args = [x for x in sys.argv[1:] if x != "--all"]
+every = "--all" in sys.argv   # every kernel of the process (a training iteration: PyTorch's kernels between the library's)
+path = args[0]
+last = int(args[1]) if len(args) > 1 else 10
 rows = []
 for r in csv.DictReader(open(path)):
     name = r["Kernel_Name"].split("(")[0].replace("void ", "")
-    if name.startswith("gsr_") or "rocclr" in name:   # the library's kernels and the runtime's copy / fill kernels between them
+    if every or name.startswith("gsr_") or "rocclr" in name:   # the library's kernels and the runtime's copy / fill kernels between them
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), name))
 rows.sort()
 starts = [i for i, r in enumerate(rows) if r[2].startswith("gsr_preprocess_kernel")]
 steps = [rows[a:b] for a, b in zip(starts[:-1], starts[1:])]
 # keep the steps of the most common length (the timed ones; per-kernel-table steps run the colour kernel in line)
 steps = [[r for r in s if not ((r[2].startswith("__amd_rocclr_fill") or r[2].startswith("gsr_zero_status")) and r is s[-1])] for s in steps]   # the next step's status zeroing
-steps = [s for s in steps if s and s[-1][2].startswith("gsr_gaussian_backward")]
+if not every:
+    steps = [s for s in steps if s and s[-1][2].startswith("gsr_gaussian_backward")]
 n = statistics.mode(len(s) for s in steps)
 steps = [s for s in steps if len(s) == n]
 # the timed steps run the colour kernel on the helper stream beside the geometry kernel; the steps of bench.py's per-kernel
