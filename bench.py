@@ -389,8 +389,12 @@ def parse_args():
                     help="N > 1: 'compact' all-gathers 3 floats/Gaussian/view and rebuilds the summed SH gradient "
                          "locally (view_parallel.GradientExchange); 'allreduce' sums all 59 floats/Gaussian.  The timed "
                          "region uses this mode; the other one is timed afterwards and reported under 'alt_exchange'")
-    ap.add_argument("--parts", type=int, default=2, help="N > 1: parts of the per-Gaussian backward whose exchange is "
-                                                         "started while the next part computes")
+    ap.add_argument("--parts", type=int, default=0, help="N > 1: parts of the per-Gaussian backward whose exchange is "
+                                                         "started while the next part computes; 0 (default) = chosen from the "
+                                                         "measured cost of a collective in this process group: 2 when a "
+                                                         "small all-reduce costs the stream less than 35 us (the second part's "
+                                                         "~70 us of kernel then hides more than its two extra collectives cost), "
+                                                         "else 1")
     ap.add_argument("--views-per-rank", type=int, default=1,
                     help="views every rank renders per step (gradient accumulation over k local views, then ONE exchange of the "
                          "59 floats/Gaussian through view_parallel.GradientBucket).  Default 1 = BASELINE.json configs[3] (one view "
@@ -565,6 +569,27 @@ def run_rank(args, rank, world, dev, phase=None, grouped=None):
         sync()
         if grouped:
             dist.barrier()
+
+    # --parts 0: from what a collective costs THIS process group (every rank measures, the maximum over the ranks decides, so
+    # all ranks cut their Gaussians alike)
+    parts_note = None
+    if args.parts <= 0:
+        args.parts = 2
+        if grouped and kviews == 1:
+            phase["now"] = "measuring the cost of a small all-reduce (choice of --parts)"
+            t = torch.zeros(256, device=dev if not args.dry_run else "cpu")
+            for _ in range(5):
+                dist.all_reduce(t)
+            sync()
+            t0 = time.perf_counter()
+            for _ in range(20):
+                dist.all_reduce(t)
+            sync()
+            cost = torch.tensor([(time.perf_counter() - t0) / 20 * 1e6], dtype=torch.float64, device=t.device)
+            dist.all_reduce(cost, op=dist.ReduceOp.MAX)
+            us = float(cost.item())
+            args.parts = 2 if us < 35.0 else 1
+            parts_note = f"--parts chosen = {args.parts}: a 1-KB all-reduce costs {us:.1f} us in this process group (threshold 35 us)"
 
     if args.dry_run:
         # plumbing rehearsal: the exchange of one step on synthetic per-part buffers, nothing else
@@ -747,6 +772,8 @@ def run_rank(args, rank, world, dev, phase=None, grouped=None):
                                 "first ~20 steps of a fresh process run up to 7 % slower); --settle-steps 0 disables"))
     if alt is not None:
         out["alt_exchange"] = alt
+    if parts_note:
+        out["parts_choice"] = parts_note
     if grouped and kviews == 1:
         parallelism = f"view-parallel x{world}, one view per rank, SH gradient exchange: {mode}, backward in {args.parts} parts"
     elif grouped:
@@ -849,13 +876,14 @@ def run_rank(args, rank, world, dev, phase=None, grouped=None):
             kern[dom].update(ms=round(avg, 4), launches=len(dom_times), measured_in="timed region",
                              GBps=round(allb[dom] / (avg * 1e-3) / 1e9, 1) if allb.get(dom) and avg > 0 else None)
         a = kern[dom]["GBps"] or 0.0
-        roofline = dict(kernel=dom, bound="valu_issue", achieved=a, peak=HBM_PEAK_GBS, unit="GB/s",
+        roofline = dict(kernel=dom, bound="hbm", binding_roof="valu_issue", achieved=a, peak=HBM_PEAK_GBS, unit="GB/s",
                         frac=round(a / HBM_PEAK_GBS, 4), traffic=pmc_traffic(dom, args.config),
                         valu_issue=valu_issue_fraction(dom, args.config, kern[dom]["ms"]),
-                        note="achieved / peak / frac are the HBM figures the contract asks for (algorithmic bytes per launch over the launch's "
-                             "duration against 8 TB/s); the roof that BINDS this kernel is vector-ALU issue (bound = valu_issue; valu_issue.frac: its "
-                             "instructions, counted by the SQ counters, over the rate this chip sustains on a stream of the same class mix, against "
-                             "its duration), so its HBM fraction is small by construction; 'kernels' lists the streaming stages with their own HBM fractions",
+                        note="bound = the roof that achieved / peak / frac of this line are measured against (the line's vocabulary is hbm | mfma: "
+                             "algorithmic bytes per launch over the launch's duration against 8 TB/s); binding_roof = the roof that actually limits "
+                             "this kernel: vector-ALU issue (valu_issue.frac: its instructions, counted by the SQ counters, over the rate this chip "
+                             "sustains on a stream of the same class mix, against its duration), so its HBM fraction is small by construction; "
+                             "'kernels' lists the streaming stages with their own HBM fractions",
                         avg_launch_ms=kern[dom]["ms"], algorithmic_bytes_per_launch=kern[dom]["algorithmic_bytes"],
                         step_algorithmic_bytes=step_bytes,
                         step_GBps=round(step_bytes / (ms_per_step * 1e-3) / 1e9, 1),

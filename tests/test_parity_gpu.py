@@ -287,15 +287,21 @@ def test_hip_sh_colour_and_gradient_match_reference_fixture_directly():
 
 
 def test_depth_sort_pass_count_follows_depth_range():
-    """The depth sort orders (depth bits - smallest depth bits) and runs only the radix passes those bits need: three
-    when the view's depth range spans fewer than 2^24 float steps (result in the ping-pong partner arrays), four
-    otherwise.  Both variants must give the oracle's order exactly (ties, culled Gaussians last)."""
+    """The depth order of the Gaussians, both ways it is produced.  Up to 2 Mi Gaussians: top-digit buckets sorted inside LDS
+    (csrc/depthsort.hip), three launches whatever the depth range, result in (depth_keys, perm).  GSR_DEBUG_RADIX_DEPTH (and
+    longer lists): global radix passes on (depth bits - smallest depth bits), only those the bits need -- three when the view's
+    depth range spans fewer than 2^24 float steps (result in the ping-pong partner arrays), four otherwise.  Every variant must
+    give the oracle's order exactly (ties, culled Gaussians last)."""
     _need_gpu()
+    from diff_gaussian_rasterization import _C
     # (a) compact depth range: camera at distance 4 from a cube of side 3 -> depths 2.5 .. 5.5
     scene = gsr_scene.make_scene(6000, -3.0, sh_degree=1, seed=13)
     cam = gsr_scene.make_camera(160, 96)
     o = util.oracle_forward(scene, cam, 1)
     h = util.hip_forward_backward(scene, cam, 1, None)
+    check_forward(h, o, cam)
+    assert h["depth_sort_result_in_alt"] == 0
+    h = util.hip_forward_backward(scene, cam, 1, None, debug=_C.DEBUG_RADIX_DEPTH)
     check_forward(h, o, cam)
     assert h["depth_sort_result_in_alt"] == 1
     # (b) depths from 0.2 to ~200: the float bits span more than 2^24 steps
@@ -308,9 +314,10 @@ def test_depth_sort_pass_count_follows_depth_range():
     o = util.oracle_forward(far, cam, 1)
     z = o["depths"][o["radii"] > 0]
     assert z.min() < 0.5 and z.max() > 100.0
-    h = util.hip_forward_backward(far, cam, 1, None)
-    check_forward(h, o, cam)
-    assert h["depth_sort_result_in_alt"] == 0
+    for dbg in (False, _C.DEBUG_RADIX_DEPTH):
+        h = util.hip_forward_backward(far, cam, 1, None, debug=dbg)
+        check_forward(h, o, cam)
+        assert h["depth_sort_result_in_alt"] == 0
 
 
 def test_smoke_entry():

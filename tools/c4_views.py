@@ -3,7 +3,7 @@ steady-state fwd+bwd time of every view.  On the 8-GPU run each rank renders one
 collective, so max / mean of the per-view step time is the load-imbalance bound of that run (what the slowest rank
 costs the others), before any exchange time.
 
-    python tools/c4_views.py gpurun_out/r3_c4_views.json
+    python tools/c4_views.py gpurun_out/r3_c4_views.json [uniform|blob|lowop]
 """
 import json
 import os
@@ -21,9 +21,14 @@ from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianR
 
 def main():
     out = sys.argv[1]
+    variant = sys.argv[2] if len(sys.argv) > 2 else "uniform"   # uniform | blob | lowop: the non-symmetric scenes of tools/skew_bench.py
     dev = torch.device("cuda:0")
     P, W, H, D, mu = gsr_scene.CONFIGS["C3"]
     scene = gsr_scene.make_scene(P, mu, D, seed=0)
+    if variant != "uniform":
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import skew_bench
+        scene = skew_bench.make_skewed_scene(variant, P, mu, D)
     to = lambda t: t.to(dev)
     params = {k: to(getattr(scene, k)).requires_grad_(True) for k in ("means3D", "shs", "opacities", "scales", "rotations")}
     views = []
@@ -71,7 +76,7 @@ def main():
                           step_ms_min=round(ms[0], 4), step_ms_max=round(ms[-1], 4)))
         print(views[-1], flush=True)
     med = [v["step_ms_median"] for v in views]
-    res = dict(workload="C4: 8 ring cameras (gsr_scene.ring_camera(k, 8), radius 4) of the C3 scene (1M Gaussians, SH deg 3, 1980x1080), "
+    res = dict(scene=variant, workload="C4: 8 ring cameras (gsr_scene.ring_camera(k, 8), radius 4) of the C3 scene (1M Gaussians, SH deg 3, 1980x1080), "
                         "rendered one after the other on one MI355X; fwd+bwd of the drop-in rasterizer, 21 timed steps after 40 settling steps",
                views=views, step_ms_mean=round(sum(med) / 8, 4), step_ms_max=max(med),
                imbalance_max_over_mean=round(max(med) / (sum(med) / 8), 4),
