@@ -4,12 +4,16 @@
 // nine fp32 atomicAdd per contributing (pixel, Gaussian) pair, all 256 lanes of a tile hitting the
 // same addresses -- the slowest atomic shape on this chip (MI355X_MICROARCH.md "Global float
 // atomics").  Here one wave64 owns the tile (render_common.h): per surviving instance each lane
-// first adds its four pixels' nine partials in registers, a butterfly of v_permlane32/16_swap + DPP
-// folds the wave, and the tile's total for this (Gaussian, tile) instance is written once, with
-// plain stores, into that instance's own 48-byte slot (slot = its position in the depth-ordered,
-// per-Gaussian-contiguous emission order).  The per-Gaussian kernel then adds each Gaussian's
-// contiguous run of slots in a fixed order: no atomics, no LDS partials, no workgroup barrier,
-// bitwise reproducible.  Per-pixel arithmetic is that of backward.cu:507-599; G and alpha come
+// first adds its four pixels' nine partials in registers; the wave then folds them through LDS --
+// lane l stores eight of them as row l of a 64 x 9-word area (odd row stride: 64 rows, 64 banks), the
+// eight lanes of group c add column c (eight rows each) and finish with three DPP steps, the ninth
+// value takes a DPP chain under that round trip (round 3; rounds 1-2 used a v_permlane32/16_swap
+// butterfly on the vector ALU, the port this kernel is bound by) -- and the tile's total for this
+// (Gaussian, tile) instance is written once, with plain stores, into that instance's own 48-byte
+// slot (slot = its position in the depth-ordered, per-Gaussian-contiguous emission order).  The
+// per-Gaussian kernel then adds each Gaussian's contiguous run of slots in a fixed order: no
+// atomics, no workgroup barrier (a wave's LDS operations execute in program order), bitwise
+// reproducible.  Per-pixel arithmetic is that of backward.cu:507-599; G and alpha come
 // from the same roundings as in the forward kernel (gsr_pair_power; the forward's pre-halved conic terms give the same
 // bits), so the products the forward formed are the ones undone here.
 #include "render_common.h"
