@@ -99,3 +99,23 @@ def test_bucket_sort_and_radix_sort_give_the_stable_argsort(name):
         np.testing.assert_array_equal(c["point_list"], a["point_list"])
         np.testing.assert_array_equal(c["ranges"], a["ranges"])
     print(f"{name}: P {P}, visible {visible}, distinct keys {len(np.unique(bits))}, R {a['R']}")
+
+
+@pytest.mark.parametrize("P", [(2 << 20), (2 << 20) + 1])
+def test_both_sides_of_the_bucket_sort_limit(P):
+    """GSR_BUCKET_SORT_MAX_P = 2 Mi Gaussians: the largest list the bucket sort takes (buckets of ~14 000: beyond the registers, shared by
+    next-digit histogram) and the smallest one that goes to the global radix passes."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    r = np.random.default_rng(P & 0xFF)
+    z = r.uniform(2.5, 5.5, P)
+    z[: P // 8] = 3.0 + r.integers(0, 300, P // 8) * 2.3841858e-07   # a slab on 300 float steps
+    scene = _scene_with_depths(P, r.permutation(z), seed=9)
+    cam = gsr_scene.make_camera(203, 117)
+    a = _run(scene, cam, 0, 0)
+    bits = a["depth_bits"]
+    want = np.argsort(bits, kind="stable").astype(np.uint32)
+    np.testing.assert_array_equal(a["perm"], want)
+    np.testing.assert_array_equal(a["sorted_depth_keys"], bits[want])
+    assert a["depth_sort_result_in_alt"] == (0 if P <= (2 << 20) else 1)
+    assert a["R"] > 0

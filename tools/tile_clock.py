@@ -110,6 +110,7 @@ def main():
     ap.add_argument("--scene", default="uniform", choices=["uniform", "blob", "lowop"],
                     help="uniform: the benchmark scene of --config; blob / lowop: the non-uniform 1M-Gaussian scenes of tools/skew_bench.py")
     ap.add_argument("--forward-key", action="store_true", help="also dispatch the forward by the work / durations just measured")
+    ap.add_argument("--backward-key-length", action="store_true", help="also dispatch the backward by the forward's key and by the tile id")
     ap.add_argument("--measured-key", action="store_true", help="also dispatch the backward by its own measured durations")
     a = ap.parse_args()
     if not os.path.exists(TWIN):
@@ -224,6 +225,29 @@ def main():
                 spans.append(span(rec))
             print(f"   by {label}: span {' / '.join(f'{x:.1f}' for x in spans)} us", file=out)
         L.gsr_debug_forward_key(None)
+    if a.backward_key_length:
+        # Does the backward need an order of its own?  Dispatch it by the FORWARD's key (range length, known before the forward) and
+        # by the tile id, and compare with its own key (staged instances = min(range, largest n_contrib), known after the forward:
+        # an order kernel of 16 us between the two blend kernels).
+        L.gsr_debug_backward_key.argtypes = [ctypes.c_void_p]
+        span = lambda rec: (rec[:, 1].max() - rec[:, 0].min()) * 0.01
+        print(f"== backward dispatched by other keys: span with the product key (staged instances) {span(b):.1f} us", file=out)
+        for label, keyv in (("range length (the forward's key)", length), ("tile id (no order)", np.arange(ntiles)[::-1].copy()), ("staged instances again", staged)):
+            key = torch.from_numpy(np.asarray(keyv).astype(np.int32)).to(dev)
+            assert L.gsr_debug_backward_key(key.data_ptr()) == 0
+            spans = []
+            for rep in range(3):
+                for _ in range(2):
+                    step()
+                torch.cuda.synchronize()
+                fnb = L.gsr_debug_tile_clock_backward
+                assert fnb(bufs["backward"].data_ptr()) == 0
+                step()
+                torch.cuda.synchronize()
+                fnb(None)
+                spans.append(span(bufs["backward"].cpu().numpy()[:ntiles]))
+            print(f"   by {label}: span {' / '.join(f'{x:.1f}' for x in spans)} us", file=out)
+        L.gsr_debug_backward_key(None)
     if a.measured_key:
         # Is a better dispatch key to be had?  Dispatch the backward by the durations just measured (three rounds: the durations
         # change with the order) and compare the launch spans.  (Measured at C3: 543 us with the product key, 629 / 594 / 592

@@ -10,8 +10,9 @@ import csv
 import statistics
 import sys
 
-args = [x for x in sys.argv[1:] if x != "--all"]
+args = [x for x in sys.argv[1:] if x not in ("--all", "--raw")]
 every = "--all" in sys.argv   # every kernel of the process (a training iteration: PyTorch's kernels between the library's)
+raw = "--raw" in sys.argv     # the last N dispatches as they are, with start / end relative to the first: overlapping streams (views in flight)
 path = args[0]
 last = int(args[1]) if len(args) > 1 else 10
 rows = []
@@ -20,6 +21,13 @@ for r in csv.DictReader(open(path)):
     if every or name.startswith("gsr_") or "rocclr" in name:   # the library's kernels and the runtime's copy / fill kernels between them
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), name))
 rows.sort()
+if raw:
+    sel = rows[-last:]
+    t0 = sel[0][0]
+    print(f"{'kernel':44s} {'start us':>9} {'end us':>9} {'dur us':>8}  (the last {len(sel)} dispatches of the run, by start time; kernels of different streams overlap)")
+    for a, b, name in sel:
+        print(f"{name[:44]:44s} {(a - t0) / 1e3:9.1f} {(b - t0) / 1e3:9.1f} {(b - a) / 1e3:8.1f}")
+    sys.exit(0)
 starts = [i for i, r in enumerate(rows) if r[2].startswith("gsr_preprocess_kernel")]
 steps = [rows[a:b] for a, b in zip(starts[:-1], starts[1:])]
 # keep the steps of the most common length (the timed ones; per-kernel-table steps run the colour kernel in line)
