@@ -18,8 +18,9 @@
 // that sort (histogram 6 -> 15 us, scatter 13 -> 25).  Measured at C3: step 1.167 -> 1.160 ms with two workgroups per CU (three:
 // 1.161, one: 1.161).  Only while the colour kernel is the shorter of the two: its time grows with P, the depth sort's barely (C5,
 // 6M Gaussians: colour 0.42 ms against 0.25 ms of sort -- there it keeps the whole chip).  (Round 4: the limit used to be a fixed
-// 40 KB of dynamic LDS, which on top of the LEAF kernel's 52 KB left ONE workgroup per CU -- 0.224 ms instead of 0.06, and the
-// training iteration's binning waited 110 us for it: profiles/r4_train_iteration_timeline_before.txt.)
+// 40 KB of dynamic LDS, which on top of the 52 KB the LEAF kernel then staged left ONE workgroup per CU -- 0.224 ms instead of 0.06, and
+// the training iteration's binning waited 110 us for it: profiles/r4_train_iteration_timeline_before.txt; the leaf kernel now stages
+// in halves like the packed one.)
 #ifndef GSR_COLOR_BESIDE_WGS
 #define GSR_COLOR_BESIDE_WGS 2
 #endif

@@ -271,6 +271,53 @@ __device__ __forceinline__ void gsr_sh_lin_load(float* __restrict__ lin, const f
 		}
 	}
 }
+// The same in two halves of 32 Gaussians, for a kernel that only READS the rows (the forward's colour kernel): every load of the
+// wave's two blocks is issued up front into registers (fetch), then each half is committed to a 6-KB LDS area -- floats
+// [0, 32 * 45) = the half's _features_rest rows, [32 * 45, 32 * 48) = its _features_dc rows; both boundaries are multiples of 16
+// bytes -- and read back by its 32 lanes.  Half the LDS per wave: six workgroups per CU instead of three.
+#define GSR_SH_LINH_DC (32 * 45)
+struct GsrShLinFetch { float4 r[12]; float dc[3]; };
+__device__ __forceinline__ void gsr_sh_lin_fetch(GsrShLinFetch& v, const float* __restrict__ dc, const float* __restrict__ rest, int wave_first, int nrows, int lane)
+{
+	const float* dcw = dc + (size_t)wave_first * 3;
+#pragma unroll
+	for (int i = 0; i < 3; i++) {
+		const int e = lane + 64 * i;
+		v.dc[i] = (e < nrows * 3) ? dcw[e] : 0.f;
+	}
+	const float* rw = rest + (size_t)wave_first * 45;
+	const int n = nrows * 45;
+#pragma unroll
+	for (int it = 0; it < 12; it++) {
+		const int e0 = (it * 64 + lane) * 4;
+		if (e0 + 3 < n) {
+			v.r[it] = *reinterpret_cast<const float4*>(rw + e0);
+		} else {
+			v.r[it] = make_float4(e0 < n ? rw[e0] : 0.f, e0 + 1 < n ? rw[e0 + 1] : 0.f, e0 + 2 < n ? rw[e0 + 2] : 0.f, 0.f);
+		}
+	}
+}
+__device__ __forceinline__ void gsr_sh_lin_commit_half(float* __restrict__ lin, const GsrShLinFetch& v, int lane, int half)
+{
+#pragma unroll
+	for (int i = 0; i < 3; i++) {
+		const int e = lane + 64 * i;   // element of the wave's 192 dc floats: rows 32 * half .. hold [96 half, 96 half + 96)
+		if (e / 96 == half) lin[GSR_SH_LINH_DC + e - 96 * half] = v.dc[i];
+	}
+#pragma unroll
+	for (int it = 0; it < 12; it++) {
+		const int f = it * 64 + lane;    // float4 of the wave's 720 rest float4: a half holds 360
+		if (f / 360 == half) *reinterpret_cast<float4*>(lin + 4 * (f - 360 * half)) = v.r[it];
+	}
+}
+// lane l (0 .. 31 inside its half) reads its row out of the half's area: the strides of gsr_sh_lin_row_get
+__device__ __forceinline__ void gsr_sh_linh_row_get(const float* __restrict__ lin, int l, float* __restrict__ row48)
+{
+#pragma unroll
+	for (int c = 0; c < 3; c++) row48[c] = lin[GSR_SH_LINH_DC + 3 * l + c];
+#pragma unroll
+	for (int j = 0; j < 45; j++) row48[3 + j] = lin[45 * l + j];
+}
 __device__ __forceinline__ void gsr_sh_lin_store(const float* __restrict__ lin, float* __restrict__ dc, float* __restrict__ rest,
                                                  int wave_first, int nrows, int lane)
 {

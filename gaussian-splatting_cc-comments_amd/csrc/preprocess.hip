@@ -175,9 +175,10 @@ __global__ void __launch_bounds__(GSR_PREPROCESS_BLOCK) gsr_preprocess_kernel(Gs
 template <bool LEAF>
 __global__ void __launch_bounds__(GSR_PREPROCESS_BLOCK) gsr_preprocess_color_kernel(GsrPreprocessArgs a, int sh_via_lds)
 {
-	// staging of the wave's SH block: the packed layout passes through in two halves of 32 rows (6.6 KB per wave, so that
-	// 4 waves per SIMD fit), the split leaf tensors as one linear 12 KB block
-	__shared__ float4 s_sh[GSR_PREPROCESS_BLOCK / 64][(LEAF ? 64 : 32) * GSR_SH_ROW4];
+	// staging of the wave's SH block in two halves of 32 rows (6.6 KB per wave, so that 4 waves per SIMD fit): the packed layout
+	// transposed, the split leaf tensors linearly (round 4: they used to pass as one 12-KB block -- three workgroups per CU, 0.097 ms
+	// against the packed kernel's 0.060, and the training iteration's binning waited for it)
+	__shared__ float4 s_sh[GSR_PREPROCESS_BLOCK / 64][32 * GSR_SH_ROW4];
 	const int idx = blockIdx.x * GSR_PREPROCESS_BLOCK + threadIdx.x;
 	GsrVec3 p_orig = {0.f, 0.f, 0.f};
 	if (idx < a.P) { p_orig.x = a.means3D[3 * idx]; p_orig.y = a.means3D[3 * idx + 1]; p_orig.z = a.means3D[3 * idx + 2]; }
@@ -189,9 +190,16 @@ __global__ void __launch_bounds__(GSR_PREPROCESS_BLOCK) gsr_preprocess_color_ker
 		const int wave_first = blockIdx.x * GSR_PREPROCESS_BLOCK + wave * 64;
 		const int nrows = min(64, a.P - wave_first);
 		if (LEAF) {
-			if (nrows > 0) gsr_sh_lin_load(reinterpret_cast<float*>(s_sh[wave]), a.shs, a.shs_rest, wave_first, nrows, lane);
-			__builtin_amdgcn_wave_barrier();
-			gsr_sh_lin_row_get(reinterpret_cast<const float*>(s_sh[wave]), lane, row);
+			GsrShLinFetch v;
+			gsr_sh_lin_fetch(v, a.shs, a.shs_rest, wave_first, max(nrows, 0), lane);  // every load in flight at once
+			float* lin = reinterpret_cast<float*>(s_sh[wave]);
+#pragma unroll
+			for (int half = 0; half < 2; half++) {
+				gsr_sh_lin_commit_half(lin, v, lane, half);
+				__builtin_amdgcn_wave_barrier();
+				if ((lane >> 5) == half) gsr_sh_linh_row_get(lin, lane & 31, row);
+				__builtin_amdgcn_wave_barrier();
+			}
 		} else {
 			float4 v[12];
 			gsr_sh_rows_fetch(v, a.shs, wave_first, max(nrows, 0), lane);  // all twelve loads in flight at once
@@ -284,13 +292,13 @@ void gsr_launch_preprocess(const GsrPreprocessArgs& a, hipStream_t s, hipEvent_t
 bool gsr_preprocess_needs_color(const GsrPreprocessArgs& a) { return a.shs && !a.colors_precomp; }
 
 // wgs_per_cu: 0 = as many workgroups per CU as fit; else the kernel is held to that many by (unused) dynamic LDS on top of its own
-// staging area (26 KB, 52 KB in leaf mode) -- while it runs beside the depth sort on the helper stream (api.hip)
+// staging area (26 KB) -- while it runs beside the depth sort on the helper stream (api.hip)
 void gsr_launch_preprocess_color(const GsrPreprocessArgs& a, hipStream_t s, int wgs_per_cu)
 {
 	const int nb = (a.P + GSR_PREPROCESS_BLOCK - 1) / GSR_PREPROCESS_BLOCK;
 	// LDS-transposed SH path: the flagship layout (16 coefficients), 16-byte aligned tensor
 	int sh_via_lds = (a.M == 16 && ((uintptr_t)a.shs & 15u) == 0) ? 1 : 0;
-	const size_t own = (size_t)(GSR_PREPROCESS_BLOCK / 64) * (a.leaf ? 64 : 32) * GSR_SH_ROW4 * sizeof(float4);
+	const size_t own = (size_t)(GSR_PREPROCESS_BLOCK / 64) * 32 * GSR_SH_ROW4 * sizeof(float4);
 	const size_t share = wgs_per_cu > 0 ? (size_t)160 * 1024 / (size_t)wgs_per_cu : 0;
 	const size_t throttle = share > own + 1024 ? share - own - 1024 : 0;   // (1 KB of slack for allocation granularity)
 	if (a.leaf) {

@@ -351,6 +351,7 @@ class ViewsInFlight:
         if in_flight < 1:
             raise ValueError("in_flight must be at least 1")
         self.device = torch.device(device)
+        # (equal priorities: with one of two streams at high priority the staggered step took 3.39 ms instead of 2.35, round 4)
         self.streams = [torch.cuda.Stream(self.device) for _ in range(in_flight)]
         # staggered: every view's forward AND backward are issued before the next view's forward, views alternating over the
         # streams -- a view's stage 1 and binning then run under the previous view's backward blend and its forward blend under
