@@ -207,7 +207,7 @@ extern "C" int gsr_geometry_layout_of(int P, gsr_geometry_layout* o)
 	o->clamped = off;        off = gsr_align_up(off + n);
 	o->sh_ddir = off;        off = gsr_align_up(off + n * 36);
 	o->status = off;         off = gsr_align_up(off + GSR_STATUS_WORDS * 4);
-	o->scan_temp = off;      off = gsr_align_up(off + gsr_align_up(nb * 4));
+	o->scan_temp = off;      off = gsr_align_up(off + 2 * gsr_align_up(nb * 4));   // depth-ordered block sums, then the preprocess workgroups' tile counts
 	o->sort_table = off;     off = gsr_align_up(off + gsr_radix_table_bytes(n));
 	o->col_table = off;      off = gsr_align_up(off + gsr_tilebin_col_table_bytes(n));
 	o->total = off;
@@ -293,6 +293,7 @@ GsrGeometry gsr_geometry_view(void* blob, int P)
 	g.sh_ddir = (float*)(b + l.sh_ddir);
 	g.status = (uint32_t*)(b + l.status);
 	g.sorted_block_sums = (uint32_t*)(b + l.scan_temp);
+	g.block_tiles = (uint32_t*)(b + l.scan_temp + gsr_align_up(((size_t)P + GSR_PREPROCESS_BLOCK - 1) / GSR_PREPROCESS_BLOCK * 4));
 	g.sort_table = (void*)(b + l.sort_table);
 	g.col_table = (void*)(b + l.col_table);
 	return g;

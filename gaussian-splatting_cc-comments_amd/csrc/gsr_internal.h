@@ -13,6 +13,8 @@
 // 9 us of serialisation); the host adds the parts after the read-back.
 #define GSR_COUNT_PARTS 64
 // status words: [0] prefiltered trap, [2] 1 = the depth sort's result is in the ping-pong partners (perm_alt, depth_keys_alt),
+// [3] 1 = slot_base is final and numbers the gradient slots in INDEX order (the bucket depth sort's first kernel did it); 0 = the
+// binning numbers them in depth order itself (tilebin.hip pass 1 / the key emission),
 // [4, 68) partial instance counts, [68, 132) partial maxima of ~depth_key, [132, 196) partial maxima of depth_key
 // (visible Gaussians only; the depth sort orders key - min, so only the bits of max - min need passes)
 #define GSR_STATUS_NEGMIN (4 + GSR_COUNT_PARTS)
@@ -32,12 +34,13 @@ struct GsrGeometry {
 	uint32_t* perm_alt;
 	uint32_t* tiles_touched;
 	uint2* rect;               // dense copy of the tile rectangle {x | y << 16, w | h << 16}: what the depth-ordered kernels gather
-	uint32_t* slot_base;       // first (Gaussian,tile) gradient slot = offset of the Gaussian's first instance in depth-ordered emission
+	uint32_t* slot_base;       // first (Gaussian,tile) gradient slot: exclusive prefix of tiles_touched in index order (status word 3) or in depth order
 	uint8_t* clamped;
 	float* sh_ddir;            // [9][P] d(colour channel c)/d(unit view direction) of the visible Gaussians (plane 3c + {x,y,z})
 	uint32_t* status;             // GSR_STATUS_* words
 
 	uint32_t* sorted_block_sums;  // per-workgroup tile counts in depth order (the key emission takes their prefix sums itself)
+	uint32_t* block_tiles;        // tile counts of the preprocess kernel's workgroups (256 Gaussians each, index order): slot_base's prefix
 	void* sort_table;             // radix histogram table for the P-sized depth sort
 	void* col_table;              // tilebin.hip, pass 1 (column pairs by tile column): chunk sums, block rows, digit totals
 };
@@ -149,7 +152,8 @@ void gsr_radix_sort_passes(void* k0, uint32_t* v0, void* k1, uint32_t* v1, size_
                            int pass_first, int pass_count, void* table_mem, const uint32_t* bias, int key_bytes, hipStream_t s);
 void gsr_radix_sort_u32(void* k0, uint32_t* v0, void* k1, uint32_t* v1, size_t n, int nbits_total, void* table_mem,
                         int* result_in_first, int clear_table, int key_bytes, hipStream_t s);
-void gsr_radix_top_pass(const uint32_t* k0, uint32_t* k1, const uint2* rec_in, uint4* rec_out, size_t n, void* table_mem, const uint32_t* bias, hipStream_t s);
+void gsr_radix_top_pass(const uint32_t* k0, uint32_t* k1, const uint2* rec_in, uint4* rec_out, size_t n, void* table_mem, const uint32_t* bias, hipStream_t s,
+                        uint32_t* slot_base, const uint32_t* block_tiles, uint32_t* status);
 int gsr_radix_top_chunks(size_t n);
 // depthsort.hip: depth order in three launches (top-digit buckets, then every bucket sorted inside LDS) for up to this many Gaussians
 #define GSR_BUCKET_SORT_MAX_P (2 << 20)

@@ -138,26 +138,45 @@ __global__ void __launch_bounds__(GSR_PREPROCESS_BLOCK) gsr_preprocess_kernel(Gs
 	// offsets that are used here are those of the depth order (gsr_sorted_block_sums_kernel)
 	// ... and, the same way, the range of the depth keys of the visible Gaussians: 64-way partial maxima of ~key and key
 	// (sort.hip orders key - min, so the depth sort only needs passes for the bits of max - min)
+	// ... and each Gaussian's first gradient slot inside its workgroup: the exclusive scan of tiles_touched over the workgroup's 256
+	// Gaussians in INDEX order (slot_base, made global by the depth sort's first kernel from the workgroups' totals in block_tiles:
+	// sort.hip).  Index order, not depth order: the per-Gaussian backward walks the Gaussians by index, so a wave's slots and their
+	// validity bytes then form ONE contiguous range instead of 64 runs on lines of their own (round 4; what the reference's
+	// InclusiveSum over tiles_touched gives, rasterizer_impl.cu:323)
 	__shared__ uint32_t wsum[GSR_PREPROCESS_BLOCK / 64], wneg[GSR_PREPROCESS_BLOCK / 64], wmax[GSR_PREPROCESS_BLOCK / 64];
-	uint32_t v = tiles;
+	uint32_t incl = tiles;
+#pragma unroll
+	for (int off = 1; off < 64; off <<= 1) {
+		const uint32_t t = __shfl_up(incl, off, 64);
+		if ((threadIdx.x & 63) >= (unsigned)off) incl += t;
+	}
 	uint32_t kneg = tiles ? ~depth_key : 0u, kmax = tiles ? depth_key : 0u;
 #pragma unroll
 	for (int off = 32; off > 0; off >>= 1) {
-		v += __shfl_down(v, off, 64);
-		kneg = max(kneg, (uint32_t)__shfl_down(kneg, off, 64));
-		kmax = max(kmax, (uint32_t)__shfl_down(kmax, off, 64));
+		kneg = max(kneg, (uint32_t)__shfl_xor(kneg, off, 64));
+		kmax = max(kmax, (uint32_t)__shfl_xor(kmax, off, 64));
 	}
-	if ((threadIdx.x & 63) == 0) { wsum[threadIdx.x >> 6] = v; wneg[threadIdx.x >> 6] = kneg; wmax[threadIdx.x >> 6] = kmax; }
+	if ((threadIdx.x & 63) == 63) { wsum[threadIdx.x >> 6] = incl; wneg[threadIdx.x >> 6] = kneg; wmax[threadIdx.x >> 6] = kmax; }
 	__syncthreads();
-	if (threadIdx.x == 0) {
-		uint32_t t = 0, n2 = 0, m2 = 0;
+	{
+		uint32_t before = 0, t = 0;
 #pragma unroll
-		for (int w = 0; w < GSR_PREPROCESS_BLOCK / 64; w++) { t += wsum[w]; n2 = max(n2, wneg[w]); m2 = max(m2, wmax[w]); }
-		if (t) {
-			const int part = blockIdx.x & (GSR_COUNT_PARTS - 1);
-			atomicAdd(&a.g.status[4 + part], t);
-			atomicMax(&a.g.status[GSR_STATUS_NEGMIN + part], n2);
-			atomicMax(&a.g.status[GSR_STATUS_MAX + part], m2);
+		for (int w = 0; w < GSR_PREPROCESS_BLOCK / 64; w++) {
+			if (w < (int)(threadIdx.x >> 6)) before += wsum[w];
+			t += wsum[w];
+		}
+		if (idx < a.P) a.g.slot_base[idx] = before + incl - tiles;
+		if (threadIdx.x == 0) {
+			a.g.block_tiles[blockIdx.x] = t;
+			uint32_t n2 = 0, m2 = 0;
+#pragma unroll
+			for (int w = 0; w < GSR_PREPROCESS_BLOCK / 64; w++) { n2 = max(n2, wneg[w]); m2 = max(m2, wmax[w]); }
+			if (t) {
+				const int part = blockIdx.x & (GSR_COUNT_PARTS - 1);
+				atomicAdd(&a.g.status[4 + part], t);
+				atomicMax(&a.g.status[GSR_STATUS_NEGMIN + part], n2);
+				atomicMax(&a.g.status[GSR_STATUS_MAX + part], m2);
+			}
 		}
 	}
 	// zero the chunk sums of the depth sort's passes (sort.hip): one word per thread of the first workgroups

@@ -60,10 +60,68 @@ __global__ void __launch_bounds__(GSR_SORT_THREADS) gsr_radix_hist_kernel(const 
                                                                           int shift, uint32_t mask,
                                                                           uint32_t* __restrict__ table, int nblocks,
                                                                           uint32_t* __restrict__ chunk_sums, int nchunks,
-                                                                          const uint32_t* __restrict__ bias, int blocks_per_wg)
+                                                                          const uint32_t* __restrict__ bias, int blocks_per_wg,
+                                                                          uint32_t* __restrict__ slot_base = nullptr,
+                                                                          const uint32_t* __restrict__ block_tiles = nullptr,
+                                                                          uint32_t* __restrict__ status = nullptr)
 {
 	__shared__ uint32_t hist[GSR_SORT_RADIX];
 	__shared__ uint32_t s_bias[2];
+	// First kernel of the bucket depth sort only (slot_base != NULL; one block per workgroup): the Gaussians' first gradient slots
+	// become global.  The preprocess kernel left slot_base[i] = exclusive scan of tiles_touched inside its workgroup of
+	// GSR_PREPROCESS_BLOCK Gaussians and the workgroups' totals in block_tiles; this block's Gaussians add the totals of every
+	// workgroup in front of theirs -- every workgroup here sums those up itself (<= P / 256 words, 16 loads in flight per thread),
+	// as cheap as the walk of the offset tables and without a scan kernel of its own.  Index order: see preprocess.hip.
+	if (slot_base) {
+		constexpr int TILE_ = GSR_SORT_THREADS * ITEMS, SUB = TILE_ / GSR_PREPROCESS_BLOCK;
+		static_assert(TILE_ % GSR_PREPROCESS_BLOCK == 0 || sizeof(KeyT) != 4, "a sort block must hold whole preprocess workgroups");
+		__shared__ uint32_t s_part[GSR_SORT_THREADS / 64], s_sub[SUB > 0 ? SUB : 1];
+		const int nb_all = (int)((n + GSR_PREPROCESS_BLOCK - 1) / GSR_PREPROCESS_BLOCK);
+		const int nb_before = (int)blockIdx.x * SUB;
+		uint32_t part = 0;
+		for (int j0 = 0; j0 < nb_before; j0 += 16 * GSR_SORT_THREADS) {
+			uint32_t t[16];
+#pragma unroll
+			for (int u = 0; u < 16; u++) {
+				const int j = j0 + u * GSR_SORT_THREADS + (int)threadIdx.x;
+				t[u] = j < nb_before ? block_tiles[j] : 0u;
+			}
+#pragma unroll
+			for (int u = 0; u < 16; u++) part += t[u];
+		}
+		const uint32_t own = ((int)threadIdx.x < SUB && nb_before + (int)threadIdx.x < nb_all) ? block_tiles[nb_before + threadIdx.x] : 0u;
+#pragma unroll
+		for (int off = 32; off > 0; off >>= 1) part += (uint32_t)__shfl_xor(part, off, 64);
+		if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = part;
+		__syncthreads();
+		if ((int)threadIdx.x < SUB) {   // (SUB <= 64: one wave) first slot of this block's sub-block `threadIdx.x`
+			uint32_t before = 0;
+#pragma unroll
+			for (int w = 0; w < GSR_SORT_THREADS / 64; w++) before += s_part[w];
+			uint32_t incl = own;
+#pragma unroll
+			for (int off = 1; off < SUB; off <<= 1) {
+				const uint32_t t = __shfl_up(incl, off, 64);
+				if ((int)threadIdx.x >= off) incl += t;
+			}
+			s_sub[threadIdx.x] = before + incl - own;
+		}
+		__syncthreads();
+		const size_t first = (size_t)blockIdx.x * TILE_;
+		for (int e0 = 4 * (int)threadIdx.x; e0 < TILE_; e0 += 4 * GSR_SORT_THREADS) {   // four consecutive Gaussians per thread: one sub-block
+			const uint32_t add = s_sub[e0 / GSR_PREPROCESS_BLOCK];
+			if (first + e0 + 3 < n) {
+				uint4* q = reinterpret_cast<uint4*>(slot_base + first + e0);
+				uint4 v = *q;
+				v.x += add; v.y += add; v.z += add; v.w += add;
+				*q = v;
+			} else {
+				for (int c = 0; c < 4; c++)
+					if (first + e0 + c < n) slot_base[first + e0 + c] += add;
+			}
+		}
+		if (blockIdx.x == 0 && threadIdx.x == 0) status[3] = 1u;   // (gsr_internal.h: slot_base is final, index order)
+	}
 	const GsrKeyBias kb = gsr_sort_bias(bias, s_bias);
 	const bool biased = bias != nullptr;
 	// the histogram does not care which thread counts which element of the block's tile: 16-byte loads (4 keys of 32 bits or
@@ -395,9 +453,11 @@ void gsr_radix_sort_passes(void* k0, uint32_t* v0, void* k1, uint32_t* v1, size_
 
 // First level of the bucket depth sort (depthsort.hip): ONE stable pass of the Gaussian-sized kernels on the top-digit bucket
 // of the biased depth keys (gsr_depth_key.h; shift = -1), values = the identity; the elements take their tile rectangles along
-// (rec_in = GsrGeometry::rect, read in index order: coalesced) and arrive as 16-byte records {rectangle, id, 0}.  Uses pass 0's slice of the chunk sums, which
+// (rec_in = GsrGeometry::rect, read in index order: coalesced) and arrive as 16-byte records {rectangle, id, 0}.  The histogram
+// kernel also makes the Gaussians' first gradient slots global (slot_base / block_tiles / status word 3: see the kernel).  Uses pass 0's slice of the chunk sums, which
 // must be zero; afterwards [chunk][digit] sums to the bucket sizes.
-void gsr_radix_top_pass(const uint32_t* k0, uint32_t* k1, const uint2* rec_in, uint4* rec_out, size_t n, void* table_mem, const uint32_t* bias, hipStream_t s)
+void gsr_radix_top_pass(const uint32_t* k0, uint32_t* k1, const uint2* rec_in, uint4* rec_out, size_t n, void* table_mem, const uint32_t* bias, hipStream_t s,
+                        uint32_t* slot_base, const uint32_t* block_tiles, uint32_t* status)
 {
 	if (n == 0) return;
 	uint32_t* chunk_sums = (uint32_t*)table_mem;
@@ -405,7 +465,8 @@ void gsr_radix_top_pass(const uint32_t* k0, uint32_t* k1, const uint2* rec_in, u
 	constexpr int ITEMS = GSR_SORT_ITEMS_SMALL;
 	const int nblocks = (int)((n + (size_t)GSR_SORT_THREADS * ITEMS - 1) / ((size_t)GSR_SORT_THREADS * ITEMS));
 	const int nchunks = gsr_radix_top_chunks(n);
-	hipLaunchKernelGGL((gsr_radix_hist_kernel<ITEMS, uint32_t>), dim3(nblocks), dim3(GSR_SORT_THREADS), 0, s, k0, n, -1, 255u, table, nblocks, chunk_sums, nchunks, bias, 1);
+	hipLaunchKernelGGL((gsr_radix_hist_kernel<ITEMS, uint32_t>), dim3(nblocks), dim3(GSR_SORT_THREADS), 0, s, k0, n, -1, 255u, table, nblocks, chunk_sums, nchunks, bias, 1,
+	                   slot_base, block_tiles, status);
 	hipLaunchKernelGGL((gsr_radix_scatter_kernel<ITEMS, uint32_t, true>), dim3(nblocks), dim3(GSR_SORT_THREADS), 0, s, k0, (const uint32_t*)nullptr, k1,
 	                   (uint32_t*)nullptr, n, -1, 8, table, nblocks, chunk_sums, nchunks, bias, rec_in, rec_out);
 }

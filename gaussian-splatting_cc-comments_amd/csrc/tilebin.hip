@@ -277,14 +277,15 @@ __global__ void __launch_bounds__(TB_THREADS) gsr_tb_col_hist_kernel(const uint3
 
 // ---- pass 1, scatter ------------------------------------------------------------------------------
 // Output: column pairs sorted by tile column, inside a column in depth order: (y0 | (h - 1) << 8, Gaussian id) as one 8-byte word.
-// Also: the Gaussians' first gradient slots (slot_base, depth-ordered numbering as before), pass 1's digit totals for pass 2's
+// Also: the Gaussians' first gradient slots (slot_base, depth-ordered numbering) unless the bucket depth sort has numbered them in
+// index order already (status word 3), pass 1's digit totals for pass 2's
 // workgroup map (workgroup 0), and zeroes for pass 2's chunk sums.
 __global__ void __launch_bounds__(TB_THREADS) gsr_tb_col_scatter_kernel(const uint4* __restrict__ seg, int P, int nblocks,
                                                                         const uint32_t* __restrict__ block_sums,
                                                                         const uint32_t* __restrict__ table, const uint32_t* __restrict__ chunk_sums,
                                                                         int nchunks, uint32_t* __restrict__ slot_base,
                                                                         uint32_t* __restrict__ col_totals, uint2* __restrict__ cpair, uint32_t capacity,
-                                                                        uint32_t* __restrict__ clear, size_t clear_words)
+                                                                        uint32_t* __restrict__ clear, size_t clear_words, const uint32_t* __restrict__ status)
 {
 	__shared__ __attribute__((aligned(16))) unsigned long long s_mask[TB_WAVES][TB_RADIX];  // the walk's partial sums first, then the ranking's peer masks
 	__shared__ __attribute__((aligned(16))) uint32_t wcount[TB_WAVES][TB_RADIX];
@@ -295,6 +296,7 @@ __global__ void __launch_bounds__(TB_THREADS) gsr_tb_col_scatter_kernel(const ui
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	for (size_t w = (size_t)blockIdx.x * TB_THREADS + threadIdx.x; w < clear_words; w += (size_t)gridDim.x * TB_THREADS) clear[w] = 0u;
 	s_flag[wave][lane] = 0u;
+	const bool slot_final = status[3] != 0u;   // the bucket depth sort has numbered the gradient slots already (index order): uniform
 	// Workgroup w takes the consecutive blocks [w per, (w + 1) per) -- one block while every block of the launch is resident at once
 	// (up to ~1 M Gaussians), several beyond -- and walks the offset tables for the first of them only (see pass 2's scatter)
 	const int per = (nblocks + (int)gridDim.x - 1) / (int)gridDim.x;
@@ -356,7 +358,7 @@ __global__ void __launch_bounds__(TB_THREADS) gsr_tb_col_scatter_kernel(const ui
 		for (int q = 0; q < TB_GROUPS; q++) {
 			uint32_t base = tiles_front;
 			for (int G = 0; G < wave * TB_GROUPS + q; G++) base += gsum[G];
-			if (tiles[q]) slot_base[id[q]] = base + incl_t[q] - tiles[q];
+			if (!slot_final && tiles[q]) slot_base[id[q]] = base + incl_t[q] - tiles[q];
 		}
 		__syncthreads();
 #pragma unroll 1
@@ -569,7 +571,7 @@ void gsr_launch_tilebin_col_scatter(GsrGeometry g, int P, GsrBinning b, int64_t 
 	const int grid = t.nblocks < 256 * 4 ? t.nblocks : 256 * 4;   // what the chip holds at once (116 VGPRs: four workgroups per CU)
 	hipLaunchKernelGGL(gsr_tb_col_scatter_kernel, dim3(grid), dim3(TB_THREADS), 0, s, t.seg, P, t.nblocks, g.sorted_block_sums, t.table, t.chunk_sums,
 	                   t.nchunks, g.slot_base, t.totals, tb_pairs(b), tb_pair_capacity(b), (uint32_t*)b.sort_table,
-	                   gsr_tilebin_row_clear_words((size_t)R));
+	                   gsr_tilebin_row_clear_words((size_t)R), (const uint32_t*)g.status);
 }
 
 void gsr_launch_tilebin_row_hist(GsrGeometry g, int P, GsrBinning b, int64_t R, hipStream_t s)

@@ -84,13 +84,14 @@ typedef struct {
 	size_t perm_alt;       /* [P] u32 sort ping-pong */
 	size_t tiles_touched;  /* [P] u32 */
 	size_t rect;           /* [P] uint2: tile rectangle {min x | min y << 16, width | height << 16} (dense copy of the record's) */
-	size_t slot_base;      /* [P] u32: first gradient slot of the Gaussian = offset of its first instance in depth-ordered emission */
+	size_t slot_base;      /* [P] u32: first gradient slot of the Gaussian: exclusive prefix of tiles_touched in index order (status word 3
+	                          = 1: up to 2 Mi Gaussians) or in (depth, id) order (status word 3 = 0); a Gaussian's slots are contiguous */
 	size_t clamped;        /* [P] u8 bit c set = colour channel c was clamped at 0 */
 	size_t sh_ddir;        /* [9][P] f32 d(colour channel c)/d(unit view direction x,y,z) of the visible Gaussians, left by the forward so
 	                          that the backward does not read the SH rows again (backward.cu:98-132) */
-	size_t status;         /* u32 device status words (0: prefiltered trap; 2: depth order in the _alt pair; 4..67: partial instance
+	size_t status;         /* u32 device status words (0: prefiltered trap; 2: depth order in the _alt pair; 3: slots numbered in index order; 4..67: partial instance
 	                          counts; 68..131 / 132..195: partial maxima of ~depth key / depth key of the visible Gaussians) */
-	size_t scan_temp;      /* per-workgroup tile counts in depth order */
+	size_t scan_temp;      /* per-workgroup tile counts in depth order, then the preprocess workgroups' tile counts in index order */
 	size_t sort_table;     /* radix histogram table of the depth sort */
 	size_t col_table;      /* column-pair binning, pass 1 (by tile column): chunk sums, per-workgroup digit rows, 256 digit totals, the
 	                          Gaussians' {rectangle, id} records in depth order and (bucket depth sort) in bucket order, 16 B each */

@@ -29,13 +29,19 @@ def check_forward(h, o, cam):
     assert h["num_rendered"] == o["num_rendered"]
     np.testing.assert_array_equal(h["radii"], o["radii"])
     np.testing.assert_array_equal(h["tiles_touched"], o["tiles_touched"])
-    # slots: exclusive prefix of tiles_touched taken in (depth, id) order
     order = np.lexsort((np.arange(P), o["depths"].view(np.uint32) | np.where(o["radii"] > 0, 0, 0xFFFFFFFF).astype(np.uint32)))
     np.testing.assert_array_equal(h["perm"], order.astype(np.uint32))
-    tt = o["tiles_touched"][order].astype(np.int64)
-    base = np.cumsum(tt) - tt
-    vis_sorted = tt > 0
-    np.testing.assert_array_equal(h["slot_base"][order][vis_sorted], base[vis_sorted].astype(np.uint32))
+    # gradient slots: a Gaussian's first slot = exclusive prefix of tiles_touched -- in index order (what the reference's InclusiveSum
+    # gives, rasterizer_impl.cu:323) when the bucket depth sort numbered them, in (depth, id) order when the binning did
+    if h["slots_in_index_order"]:
+        tt = o["tiles_touched"].astype(np.int64)
+        base = np.cumsum(tt) - tt
+        np.testing.assert_array_equal(h["slot_base"][tt > 0], base[tt > 0].astype(np.uint32))
+    else:
+        tt = o["tiles_touched"][order].astype(np.int64)
+        base = np.cumsum(tt) - tt
+        vis_sorted = tt > 0
+        np.testing.assert_array_equal(h["slot_base"][order][vis_sorted], base[vis_sorted].astype(np.uint32))
     vis = o["radii"] > 0
     # per-Gaussian floats: bit-exact (same expression order, no FMA contraction on either side)
     for k in ("means2D", "conic_opacity", "rgb", "depths"):
