@@ -45,6 +45,10 @@
 #define DS_BATCH 8                         // loads a lane keeps in flight in the traversals of a bucket (round trips to L2, not bytes)
 #define DS_GRID_PER_CU 3                   // workgroups a CU holds (LDS)
 
+// a value every lane of the wave holds alike, as a scalar: the branches and loops it steers are then scalar branches, not
+// exec-masked regions with workgroup barriers inside
+#define DS_UNIFORM(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
+
 struct DsLds {
 	uint32_t key[2][DS_CAP];                  // key' of the elements being sorted
 	uint16_t idx[2][DS_CAP];                  // their positions in the bucket (one item, parts) or in the collected sequence (shared)
@@ -64,7 +68,7 @@ struct DsLds {
 };
 
 // exclusive scan of v over threads 0 .. 255 (thread d -> sum of v of threads < d); every thread of the workgroup calls it, the
-// result is meaningful for threads < 256.  Contains two __syncthreads().
+// result is meaningful for threads < 256.  Contains two gsr_sync().
 __device__ __forceinline__ uint32_t ds_scan_256(uint32_t v, uint32_t* wsum4, uint32_t* total = nullptr)
 {
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -75,7 +79,7 @@ __device__ __forceinline__ uint32_t ds_scan_256(uint32_t v, uint32_t* wsum4, uin
 		if (lane >= off) incl += t;
 	}
 	if (wave < 4 && lane == 63) wsum4[wave] = incl;
-	__syncthreads();
+	gsr_sync();
 	uint32_t wb = 0, tot = 0;
 #pragma unroll
 	for (int w = 0; w < 4; w++) {
@@ -84,7 +88,7 @@ __device__ __forceinline__ uint32_t ds_scan_256(uint32_t v, uint32_t* wsum4, uin
 		tot += s;
 	}
 	if (total) *total = tot;
-	__syncthreads();
+	gsr_sync();
 	return wb + incl - v;
 }
 
@@ -122,6 +126,8 @@ __device__ __forceinline__ bool ds_selected(uint32_t kp, uint32_t mask, uint32_t
 // elements, visits it 64 at a time, and the lanes that hold the same digit find each other through a 64-bit word in LDS.
 __device__ __forceinline__ int ds_sort_lds(DsLds& L, uint32_t cnt, uint32_t bits)
 {
+	cnt = DS_UNIFORM(cnt);
+	bits = DS_UNIFORM(bits);
 	const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	const uint32_t run64 = (cnt + DS_THREADS - 1) / DS_THREADS * 64;   // a wave's run
 	const uint32_t rounds = run64 / 64;                                 // <= DS_ROUNDS (cnt <= DS_CAP)
@@ -161,7 +167,7 @@ __device__ __forceinline__ int ds_sort_lds(DsLds& L, uint32_t cnt, uint32_t bits
 				rank[it] = old + below;
 			}
 		}
-		__syncthreads();
+		gsr_sync();
 		{   // thread d < 256: first position of digit d, then of each wave's part of it
 			uint32_t tot = 0;
 			if (threadIdx.x < 256) {
@@ -178,7 +184,7 @@ __device__ __forceinline__ int ds_sort_lds(DsLds& L, uint32_t cnt, uint32_t bits
 				}
 			}
 		}
-		__syncthreads();
+		gsr_sync();
 #pragma unroll
 		for (uint32_t it = 0; it < DS_ROUNDS; it++)
 			if (it < rounds) {
@@ -189,7 +195,7 @@ __device__ __forceinline__ int ds_sort_lds(DsLds& L, uint32_t cnt, uint32_t bits
 					if (pos < DS_CAP) { L.key[src ^ 1][pos] = k; L.idx[src ^ 1][pos] = L.idx[src][i]; }
 				}
 			}
-		__syncthreads();
+		gsr_sync();
 	}
 	return src;
 }
@@ -230,7 +236,7 @@ __global__ void __launch_bounds__(DS_THREADS) gsr_ds_bucket_kernel(const uint32_
 		for (int c0 = 0; c0 < nchunks; c0 += 16) {
 			uint32_t t[16];
 #pragma unroll
-			for (int j = 0; j < 16; j++) t[j] = (c0 + j < nchunks) ? chunk_sums[(size_t)(c0 + j) * 256 + threadIdx.x] : 0u;
+			for (int j = 0; j < 16; j++) t[j] = (c0 + j < nchunks) ? chunk_sums[(size_t)(c0 + j) * 256 + threadIdx.x] : 0u;   // (rows of the depth sort's table: nchunks is the host's)
 #pragma unroll
 			for (int j = 0; j < 16; j++) n_d += t[j];
 		}
@@ -243,15 +249,14 @@ __global__ void __launch_bounds__(DS_THREADS) gsr_ds_bucket_kernel(const uint32_
 	const uint32_t off_d = ds_scan_256(n_d, L.wsum);
 	uint32_t items;
 	const uint32_t first_d = ds_scan_256(m_d, L.wsum, &items);
+	items = DS_UNIFORM(items);
 
 	for (uint32_t item = blockIdx.x; item < items; item += gridDim.x) {   // (uniform)
-		__syncthreads();   // (the previous item is done with LDS)
+		gsr_sync();   // (the previous item is done with LDS)
 		if (threadIdx.x < 256 && item >= first_d && item < first_d + m_d) { L.tab[0] = off_d; L.tab[1] = n_d; L.tab[2] = first_d; L.tab[3] = threadIdx.x; L.tab[4] = (copy_d || n_d <= DS_CAP) ? 1u : ds_parts_of(n_d, wbits1); }
-		__syncthreads();
-		const uint32_t off = L.tab[0], n = L.tab[1], j = item - L.tab[2], bucket = L.tab[3], parts = L.tab[4];
+		gsr_sync();
+		const uint32_t off = DS_UNIFORM(L.tab[0]), n = DS_UNIFORM(L.tab[1]), j = DS_UNIFORM(item - L.tab[2]), bucket = DS_UNIFORM(L.tab[3]), parts = DS_UNIFORM(L.tab[4]);
 		if (off > P || n > P - off) continue;   // inconsistent tables
-		const uint32_t* __restrict__ bkeys = keys_in + off;
-		const uint4* __restrict__ brecs = recs_in + off;
 
 		if (bucket == kb.culled_digit || s == 0u) {   // nothing to sort: piece j of the bucket as it is
 			const uint32_t i0 = j * DS_CAP;
@@ -260,8 +265,8 @@ __global__ void __launch_bounds__(DS_THREADS) gsr_ds_bucket_kernel(const uint32_
 #pragma unroll
 			for (int u = 0; u < DS_ROUNDS; u++) {
 				const uint32_t i = i0 + u * DS_THREADS + threadIdx.x;
-				k[u] = i < n ? bkeys[i] : 0xFFFFFFFFu;
-				rec[u] = i < n ? brecs[i] : make_uint4(0u, 0u, 0u, 0u);
+				k[u] = i < n ? keys_in[off + i] : 0xFFFFFFFFu;
+				rec[u] = i < n ? recs_in[off + i] : make_uint4(0u, 0u, 0u, 0u);
 			}
 #pragma unroll
 			for (int u = 0; u < DS_ROUNDS; u++) {
@@ -277,7 +282,7 @@ __global__ void __launch_bounds__(DS_THREADS) gsr_ds_bucket_kernel(const uint32_
 #pragma unroll
 				for (int u = 0; u < DS_ROUNDS; u++) {
 					const uint32_t i = u * DS_THREADS + threadIdx.x;
-					k[u] = i < n ? bkeys[i] : 0u;
+					k[u] = i < n ? keys_in[off + i] : 0u;
 				}
 #pragma unroll
 				for (int u = 0; u < DS_ROUNDS; u++) {
@@ -285,7 +290,7 @@ __global__ void __launch_bounds__(DS_THREADS) gsr_ds_bucket_kernel(const uint32_
 					if (i < n) { L.key[0][i] = k[u] - kb.min; L.idx[0][i] = (uint16_t)i; }
 				}
 			}
-			__syncthreads();
+			gsr_sync();
 			const int buf = ds_sort_lds(L, n, s);
 			// the records through the positions: one gather inside the bucket
 			uint32_t kp[DS_ROUNDS];
@@ -294,7 +299,7 @@ __global__ void __launch_bounds__(DS_THREADS) gsr_ds_bucket_kernel(const uint32_
 			for (int u = 0; u < DS_ROUNDS; u++) {
 				const uint32_t r = u * DS_THREADS + threadIdx.x;
 				kp[u] = r < n ? L.key[buf][r] : 0u;
-				rec[u] = r < n ? brecs[L.idx[buf][r]] : make_uint4(0u, 0u, 0u, 0u);
+				rec[u] = r < n ? recs_in[off + L.idx[buf][r]] : make_uint4(0u, 0u, 0u, 0u);
 			}
 #pragma unroll
 			for (int u = 0; u < DS_ROUNDS; u++) {
@@ -307,18 +312,20 @@ __global__ void __launch_bounds__(DS_THREADS) gsr_ds_bucket_kernel(const uint32_
 		// ---- shared bucket ---------------------------------------------------------------------------------------------
 		uint32_t first, last;
 		ds_wave_part(n, first, last);
+		first = DS_UNIFORM(first);   // (the same in every lane of the wave: the traversals below are scalar loops)
+		last = DS_UNIFORM(last);
 		uint32_t* const sval = L.val;   // positions in the bucket of the collected elements
 
 		// histogram of a level's digit over the elements (key' & mask) == value, counted per wave over the wave's part of the
 		// bucket (L.wcount[wave][digit], which the ranking does not need yet), and its prefix sums: L.hist[lv], L.cum[lv][0 .. 256]
 		auto histogram = [&](int lv, uint32_t mask, uint32_t value, uint32_t sh, uint32_t wmask) {
-			__syncthreads();
+			gsr_sync();
 			reinterpret_cast<uint4*>(L.wcount[wave])[lane] = make_uint4(0u, 0u, 0u, 0u);
 			__builtin_amdgcn_wave_barrier();
 			for (uint32_t i0 = first; i0 < last; i0 += 64 * DS_BATCH) {
 				uint32_t k[DS_BATCH];
 #pragma unroll
-				for (int u = 0; u < DS_BATCH; u++) { const uint32_t i = i0 + u * 64 + lane; k[u] = i < last ? bkeys[i] : 0u; }
+				for (int u = 0; u < DS_BATCH; u++) { const uint32_t i = i0 + u * 64 + lane; k[u] = i < last ? keys_in[off + i] : 0u; }
 #pragma unroll
 				for (int u = 0; u < DS_BATCH; u++) {
 					const uint32_t i = i0 + u * 64 + lane;
@@ -326,7 +333,7 @@ __global__ void __launch_bounds__(DS_THREADS) gsr_ds_bucket_kernel(const uint32_
 					if (i < last && (kp & mask) == value) atomicAdd(&L.wcount[wave][(kp >> sh) & wmask], 1u);
 				}
 			}
-			__syncthreads();
+			gsr_sync();
 			uint32_t h = 0;
 			if (threadIdx.x < 256) {
 #pragma unroll
@@ -336,7 +343,7 @@ __global__ void __launch_bounds__(DS_THREADS) gsr_ds_bucket_kernel(const uint32_
 			const uint32_t e = ds_scan_256(h, L.wsum);
 			if (threadIdx.x < 256) L.cum[lv][threadIdx.x] = e;
 			if (threadIdx.x == 255) L.cum[lv][256] = e + h;
-			__syncthreads();
+			gsr_sync();
 		};
 		// Stable compaction of the selected elements: into LDS (key', collected position, id; at most DS_SHARE_CAP of them -- the
 		// caller knows their number from a histogram) or, to_global, straight to their output positions (identical keys:
@@ -348,17 +355,17 @@ __global__ void __launch_bounds__(DS_THREADS) gsr_ds_bucket_kernel(const uint32_
 				for (uint32_t i0 = first; i0 < last; i0 += 64 * DS_BATCH) {
 					uint32_t k[DS_BATCH];
 #pragma unroll
-					for (int u = 0; u < DS_BATCH; u++) { const uint32_t i = i0 + u * 64 + lane; k[u] = i < last ? bkeys[i] : 0u; }
+					for (int u = 0; u < DS_BATCH; u++) { const uint32_t i = i0 + u * 64 + lane; k[u] = i < last ? keys_in[off + i] : 0u; }
 #pragma unroll
 					for (int u = 0; u < DS_BATCH; u++) {
 						const uint32_t i = i0 + u * 64 + lane;
 						c += (uint32_t)__popcll(__ballot(i < last && ds_selected(k[u] - kb.min, mask, value, sh, wmask, lo, hi)));
 					}
 				}
-				__syncthreads();   // (the previous users of wcnt are done)
+				gsr_sync();   // (the previous users of wcnt are done)
 				if (lane == 0) L.wcnt[wave] = c;
 			}
-			__syncthreads();   // (... and those of the key / idx buffers)
+			gsr_sync();   // (... and those of the key / idx buffers)
 			uint32_t run = 0, total = 0;
 #pragma unroll
 			for (uint32_t w = 0; w < DS_WAVES; w++) {
@@ -369,7 +376,7 @@ __global__ void __launch_bounds__(DS_THREADS) gsr_ds_bucket_kernel(const uint32_
 			for (uint32_t i0 = first; i0 < last; i0 += 64 * DS_BATCH) {
 				uint32_t k[DS_BATCH];
 #pragma unroll
-				for (int u = 0; u < DS_BATCH; u++) { const uint32_t i = i0 + u * 64 + lane; k[u] = i < last ? bkeys[i] : 0u; }
+				for (int u = 0; u < DS_BATCH; u++) { const uint32_t i = i0 + u * 64 + lane; k[u] = i < last ? keys_in[off + i] : 0u; }
 #pragma unroll
 				for (int u = 0; u < DS_BATCH; u++) {
 					const uint32_t i = i0 + u * 64 + lane;
@@ -378,14 +385,14 @@ __global__ void __launch_bounds__(DS_THREADS) gsr_ds_bucket_kernel(const uint32_
 					const unsigned long long m = __ballot(p);
 					const uint32_t pos = run + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 					if (p) {
-						if (to_global) ds_emit(keys_out, perm_out, seg, P, out_pos + pos, k[u], brecs[i]);
+						if (to_global) ds_emit(keys_out, perm_out, seg, P, out_pos + pos, k[u], recs_in[off + i]);
 						else if (pos < DS_SHARE_CAP) { L.key[0][pos] = kp; L.idx[0][pos] = (uint16_t)pos; sval[pos] = i; }
 					}
 					run += (uint32_t)__popcll(m);
 				}
 			}
-			__syncthreads();
-			return total;
+			gsr_sync();
+			return DS_UNIFORM(total);
 		};
 		// sort the collected elements on their low `bits` bits and write them to the output positions from pos0 on
 		auto sort_and_write = [&](uint32_t cnt, uint32_t bits, uint32_t pos0) {
@@ -397,7 +404,7 @@ __global__ void __launch_bounds__(DS_THREADS) gsr_ds_bucket_kernel(const uint32_
 			for (int u = 0; u < DS_SHARE_CAP / DS_THREADS; u++) {
 				const uint32_t r = u * DS_THREADS + threadIdx.x;
 				kp[u] = r < cnt ? L.key[buf][r] : 0u;
-				rec[u] = r < cnt ? brecs[sval[L.idx[buf][r]]] : make_uint4(0u, 0u, 0u, 0u);
+				rec[u] = r < cnt ? recs_in[off + sval[L.idx[buf][r]]] : make_uint4(0u, 0u, 0u, 0u);
 			}
 #pragma unroll
 			for (int u = 0; u < DS_SHARE_CAP / DS_THREADS; u++) {
@@ -421,12 +428,12 @@ __global__ void __launch_bounds__(DS_THREADS) gsr_ds_bucket_kernel(const uint32_
 				if ((uint32_t)u < rounds) {   // (uniform)
 					const uint32_t i = lane_first + u;
 					if ((uint32_t)u + 3 < rounds && i + 3 < last) {
-						const DsWords4 v = *reinterpret_cast<const DsWords4*>(bkeys + i);
+						const DsWords4 v = *reinterpret_cast<const DsWords4*>(keys_in + off + i);
 						k[u] = v.x; k[u + 1] = v.y; k[u + 2] = v.z; k[u + 3] = v.w;
 					} else {
 #pragma unroll
 						for (int c = 0; c < 4; c++)
-							if ((uint32_t)(u + c) < rounds && i + c < last) k[u + c] = bkeys[i + c];
+							if ((uint32_t)(u + c) < rounds && i + c < last) k[u + c] = keys_in[off + i + c];
 					}
 				}
 			}
@@ -452,7 +459,7 @@ __global__ void __launch_bounds__(DS_THREADS) gsr_ds_bucket_kernel(const uint32_
 			// workgroup per CU)
 #pragma unroll
 			for (int u = 0; u < DS_REG_ROUNDS; u++) asm volatile("" : "+v"(k[u]));
-			__syncthreads();
+			gsr_sync();
 			uint32_t run = incl - c_mine, mine = 0, below = 0;
 #pragma unroll
 			for (uint32_t w = 0; w < DS_WAVES; w++) {
@@ -460,6 +467,8 @@ __global__ void __launch_bounds__(DS_THREADS) gsr_ds_bucket_kernel(const uint32_
 				mine += L.wcnt[w];
 				below += L.wsum[w];
 			}
+			mine = DS_UNIFORM(mine);
+			below = DS_UNIFORM(below);
 			if (mine == 0u) continue;   // (uniform)
 			if (mine <= DS_CAP) {
 #pragma unroll
@@ -468,7 +477,7 @@ __global__ void __launch_bounds__(DS_THREADS) gsr_ds_bucket_kernel(const uint32_
 					if (p && run < DS_CAP) { L.key[0][run] = k[u] - kb.min; L.idx[0][run] = (uint16_t)(lane_first + u); }
 					run += p ? 1u : 0u;
 				}
-				__syncthreads();
+				gsr_sync();
 				const int buf = ds_sort_lds(L, mine, s);
 				uint32_t kp[DS_ROUNDS];
 				uint4 rec[DS_ROUNDS];
@@ -476,7 +485,7 @@ __global__ void __launch_bounds__(DS_THREADS) gsr_ds_bucket_kernel(const uint32_
 				for (int u = 0; u < DS_ROUNDS; u++) {
 					const uint32_t r = u * DS_THREADS + threadIdx.x;
 					kp[u] = r < mine ? L.key[buf][r] : 0u;
-					rec[u] = r < mine ? brecs[L.idx[buf][r]] : make_uint4(0u, 0u, 0u, 0u);
+					rec[u] = r < mine ? recs_in[off + L.idx[buf][r]] : make_uint4(0u, 0u, 0u, 0u);
 				}
 #pragma unroll
 				for (int u = 0; u < DS_ROUNDS; u++) {
@@ -498,14 +507,14 @@ __global__ void __launch_bounds__(DS_THREADS) gsr_ds_bucket_kernel(const uint32_
 				atomicMin(&L.vlo, threadIdx.x);
 				atomicMax(&L.vhi, threadIdx.x + 1u);
 			}
-			__syncthreads();
-			lo1 = L.vlo;
-			hi1 = L.vhi;
+			gsr_sync();
+			lo1 = DS_UNIFORM(L.vlo);
+			hi1 = DS_UNIFORM(L.vhi);
 			if (lo1 >= hi1) continue;   // (uniform)
 			if (L.cum[0][hi1] - L.cum[0][lo1] <= DS_SHARE_CAP) {
 				// (almost always) one group: the waves' counts follow from the per-wave histogram, no counting traversal
 				if (threadIdx.x < DS_WAVES) L.wcnt[threadIdx.x] = 0u;
-				__syncthreads();
+				gsr_sync();
 				if (threadIdx.x >= lo1 && threadIdx.x < hi1) {
 #pragma unroll
 					for (int w = 0; w < DS_WAVES; w++)
@@ -527,24 +536,24 @@ __global__ void __launch_bounds__(DS_THREADS) gsr_ds_bucket_kernel(const uint32_
 		}
 		int level = 1;
 		while (level >= 1) {   // (uniform: everything it tests lives in LDS)
-			__syncthreads();
-			const uint32_t v = L.st_v[level], hi = L.st_hi[level];
+			gsr_sync();
+			const uint32_t v = DS_UNIFORM(L.st_v[level]), hi = DS_UNIFORM(L.st_hi[level]);
 			if (v >= hi) { level--; continue; }
-			const uint32_t mask = L.st_mask[level], value = L.st_value[level], sh = L.st_sh[level], wbits = L.st_wbits[level];
+			const uint32_t mask = DS_UNIFORM(L.st_mask[level]), value = DS_UNIFORM(L.st_value[level]), sh = DS_UNIFORM(L.st_sh[level]), wbits = DS_UNIFORM(L.st_wbits[level]);
 			const uint32_t wmask = (1u << wbits) - 1u;
 			const uint32_t* cum = L.cum[level - 1];
-			const uint32_t c0 = cum[v];
+			const uint32_t c0 = DS_UNIFORM(cum[v]);
 			uint32_t e = hi;
-			if (cum[hi] - c0 > DS_SHARE_CAP) {   // the largest e with cum[e] - cum[v] <= DS_SHARE_CAP
-				uint32_t a = v, z = hi;           // cum[a] - c0 <= DS_SHARE_CAP < cum[z] - c0
+			if (DS_UNIFORM(cum[hi]) - c0 > DS_SHARE_CAP) {   // the largest e with cum[e] - cum[v] <= DS_SHARE_CAP
+				uint32_t a = v, z = hi;                       // cum[a] - c0 <= DS_SHARE_CAP < cum[z] - c0
 				while (z - a > 1) {
 					const uint32_t m = (a + z) / 2;
-					if (cum[m] - c0 <= DS_SHARE_CAP) a = m; else z = m;
+					if (DS_UNIFORM(cum[m]) - c0 <= DS_SHARE_CAP) a = m; else z = m;
 				}
 				e = a;
 			}
-			const uint32_t pos0 = L.st_base[level] + (c0 - cum[L.st_lo[level]]);
-			__syncthreads();   // (every thread has read the level's state)
+			const uint32_t pos0 = DS_UNIFORM(L.st_base[level] + (c0 - cum[L.st_lo[level]]));
+			gsr_sync();   // (every thread has read the level's state)
 			if (e == v) {      // value v alone exceeds DS_SHARE_CAP
 				const uint32_t m2 = mask | (wmask << sh), v2 = value | (v << sh);
 				if (threadIdx.x == 0) L.st_v[level] = v + 1u;

@@ -11,6 +11,20 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// __syncthreads() with the release fence's wait spelled out.  __syncthreads() is fence(release) + s_barrier + fence(acquire),
+// and the release fence has to become `s_waitcnt lgkmcnt(0)` whenever one of the wave's own LDS writes may still be in flight:
+// the other waves of the workgroup sit on other SIMDs with their own path into the LDS and can otherwise read the old value
+// after the barrier.  hipcc 7.2 drops that wait on one loop back edge of depthsort.hip (thread 0 stores the next level's state,
+// the loop head's barrier follows with nothing in between): once in ten runs of a scene with 45 000 equal depths per bucket
+// the other three waves read the previous item's state, left the level loop early, and from then on the workgroup's barriers
+// paired up wrongly -- missing output, then wild indices ("The stale level state").  tools/barrier_audit.py
+// (`make audit`) checks every s_barrier of the library's ISA for this; the depth sort uses gsr_sync() throughout.
+__device__ __forceinline__ void gsr_sync()
+{
+	asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+	__syncthreads();
+}
+
 struct GsrKeyBias {
 	uint32_t min, culled;      // culled = value that stands for 0xFFFFFFFF keys = (max - min) + 1
 	// top-digit mode (depthsort.hip): visible keys fall into buckets key' >> top_shift = 0 .. culled_digit - 1 (at most 255 of

@@ -125,3 +125,34 @@ def test_both_sides_of_the_bucket_sort_limit(P):
     np.testing.assert_array_equal(a["sorted_depth_keys"], bits[want])
     assert a["depth_sort_result_in_alt"] == (0 if P <= (2 << 20) else 1)
     assert a["R"] > 0
+
+
+def test_few_distinct_depths_sort_the_same_every_time():
+    """Round-4 regression (tools/depth_sort_stress.py case 156): 318 498 Gaussians on seven distinct depths -- buckets of 45 000
+    identical keys, which the bucket sort takes down its next-digit levels to a plain copy.  One run in ten left three of a
+    workgroup's four waves with a stale level state (the compiler had dropped the LDS wait in front of the level loop's barrier:
+    gsr_depth_key.h, gsr_sync(); DESIGN.md "The stale level state") and their part of the bucket unwritten.  The order must be the
+    stable argsort, and the same in every one of 40 runs."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    r = np.random.default_rng(500000 + 156)
+    P = int(np.exp(r.uniform(np.log(1), np.log(600_000))))
+    r.integers(0, 7)
+    z = r.choice(r.uniform(0.5, 50.0, int(r.integers(1, 9))), P)
+    assert P == 318498 and len(np.unique(z)) == 7
+    scene = _scene_with_depths(P, z.copy(), seed=156)
+    cam = gsr_scene.make_camera(203, 117)
+    first = None
+    for it in range(40):
+        a = _run(scene, cam, 0, 0)
+        if first is None:
+            bits = a["depth_bits"]
+            want = np.argsort(bits, kind="stable").astype(np.uint32)
+            first = a
+            np.testing.assert_array_equal(a["perm"], want)
+            np.testing.assert_array_equal(a["sorted_depth_keys"], bits[want])
+            assert a["R"] > 0
+            continue
+        assert a["R"] == first["R"], f"run {it}"
+        for k in ("perm", "sorted_depth_keys", "point_list", "ranges"):
+            np.testing.assert_array_equal(a[k], first[k], err_msg=f"run {it}: {k}")
