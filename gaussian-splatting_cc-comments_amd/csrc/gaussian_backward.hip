@@ -120,16 +120,33 @@ __device__ __forceinline__ void gsr_cov3d_backward(const float* scale, float mod
 }
 
 // Fixed-order sum of one Gaussian's contiguous run of per-tile gradient slots.  Runs of up to
-// GSR_SLOT_COOP slots (a multiple of 6) are added by the owning lane; longer runs (a big splat can own > 1000) are
+// GSR_SLOT_COOP slots are added by the owning lane; longer runs (a big splat can own > 1000) are
 // added by the whole wave, lanes striding over the run, then reduced with DPP -- so the wave's
 // time no longer follows its single most-loaded lane.  The order is fixed: bitwise reproducible.
-#define GSR_SLOT_COOP 18   // swept on MI355X at C3: 12 / 18 / 24 / 36 -> 0.172 / 0.164 / 0.166 / 0.171 ms
+#ifndef GSR_SLOT_COOP
+#define GSR_SLOT_COOP 30   // swept on MI355X at C3: 12 / 18 / 24 / 36 -> 0.172 / 0.164 / 0.166 / 0.171 ms with the slots in depth order (round 2);
+                           // in index order (round 4) a lane's records lie next to its neighbours': 18 / 30 / 58 -> 0.130 / 0.120 / 0.118 ms at C3,
+                           // 0.745 / 0.626 / 0.628 at C5
+#endif
 #define GSR_NACC 9
 #ifndef GSR_SLOT_ROUND
 #define GSR_SLOT_ROUND 6   // slot records requested per round of the per-lane sum
 #endif
 #define GSR_VALID_WORDS ((GSR_SLOT_COOP + 3 + 3) / 4)  // aligned dwords that cover GSR_SLOT_COOP bytes at any byte offset
+// one bit per slot of a lane's run: 32 bits up to 30 slots, 64 beyond (4 GSR_VALID_WORDS <= 64 bits: at most 58 slots)
+#if GSR_SLOT_COOP <= 30
+typedef uint32_t GsrSlotMask;
+__device__ __forceinline__ uint32_t gsr_slot_mask_first(uint32_t m) { return (uint32_t)__builtin_ctz(m | 0x80000000u); }
+#else
+static_assert(GSR_SLOT_COOP <= 58, "the validity bits of a lane's run must fit 64 bits");
+typedef unsigned long long GsrSlotMask;
+__device__ __forceinline__ uint32_t gsr_slot_mask_first(unsigned long long m) { return (uint32_t)__builtin_ctzll(m | 0x8000000000000000ull); }
+#endif
 
+// One slot of a long run (added by the whole wave, lanes striding over the run).  The validity byte is awaited before the record is
+// requested: asking for both at once -- the record of an invalid slot is readable garbage -- saves a round trip per 64 slots and
+// was measured in round 4: per-Gaussian backward 0.120 -> 0.129 ms at C3, 0.63 -> 0.80 at C5 (the records of the invalid slots are
+// traffic, and four more 16-byte registers in flight cost a wave per SIMD).
 __device__ __forceinline__ void gsr_add_slot(const GsrGradSlot* __restrict__ slots, const uint8_t* __restrict__ valid,
                                              uint32_t s, float* acc)
 {
@@ -198,7 +215,7 @@ __global__ void __launch_bounds__(GSR_GB_THREADS) gsr_gaussian_backward_kernel(G
 	// ---- (C) validity bytes of all the slots a lane sums by itself: its <= GSR_SLOT_COOP bytes sit in at most
 	//      GSR_VALID_WORDS consecutive aligned dwords (every lane's loads go to lines of its own, so the cost of this step
 	//      is its number of load instructions: 6 instead of 18).  Bytes are 0 or 1 (render_backward.hip / tile_ranges).
-	uint32_t vmask = 0;
+	GsrSlotMask vmask = 0;
 	if (tiles > 0 && tiles <= GSR_SLOT_COOP) {
 		const uint32_t lead = base & 3u;
 		const uint32_t* vp = reinterpret_cast<const uint32_t*>(a.slot_valid + (base - lead));  // slot_valid itself is 128-byte aligned
@@ -211,7 +228,7 @@ __global__ void __launch_bounds__(GSR_GB_THREADS) gsr_gaussian_backward_kernel(G
 			const uint32_t b4 = (w[i] & 1u) | ((w[i] >> 7) & 2u) | ((w[i] >> 14) & 4u) | ((w[i] >> 21) & 8u);
 			bits |= (unsigned long long)b4 << (4 * i);
 		}
-		vmask = (uint32_t)(bits >> lead) & ((1u << tiles) - 1u);
+		vmask = (GsrSlotMask)(bits >> lead) & (((GsrSlotMask)1 << tiles) - (GsrSlotMask)1);
 	}
 	// ---- (E) fixed-order sum of this Gaussian's (Gaussian,tile) slots: its VALID slots in ascending order, six per round;
 	//      the records of a round are all requested before the first add, and only by the lanes that have one (a lane's
@@ -219,16 +236,16 @@ __global__ void __launch_bounds__(GSR_GB_THREADS) gsr_gaussian_backward_kernel(G
 	float acc[GSR_NACC];
 #pragma unroll
 	for (int i = 0; i < GSR_NACC; i++) acc[i] = 0.f;
-	uint32_t rem = vmask;
+	GsrSlotMask rem = vmask;
 	while (rem) {
 		float4 s0[GSR_SLOT_ROUND], s1[GSR_SLOT_ROUND];
 		float s2[GSR_SLOT_ROUND];
 		bool ok[GSR_SLOT_ROUND];
 #pragma unroll
 		for (int j = 0; j < GSR_SLOT_ROUND; j++) {
-			ok[j] = rem != 0u;
-			const uint32_t k = (uint32_t)__builtin_ctz(rem | 0x80000000u);
-			rem &= rem - 1u;
+			ok[j] = rem != 0;
+			const uint32_t k = gsr_slot_mask_first(rem);
+			rem &= rem - (GsrSlotMask)1;
 			if (ok[j]) {
 				const float4* sl = reinterpret_cast<const float4*>(a.slots + (base + k));
 				s0[j] = sl[0]; s1[j] = sl[1]; s2[j] = sl[2].x;
