@@ -143,6 +143,11 @@ typedef unsigned long long GsrSlotMask;
 __device__ __forceinline__ uint32_t gsr_slot_mask_first(unsigned long long m) { return (uint32_t)__builtin_ctzll(m | 0x8000000000000000ull); }
 #endif
 
+// (Also measured in round 4 and rejected: the wave's 64 runs -- contiguous in memory with the slots in index order -- read as one flat
+// stream of 16-byte loads into LDS, nine words per record, every lane then adding its own records from there in the same order.
+// Bit-identical results; 0.124 -> 0.184 ms at C3 with four loads in flight per lane, 0.207 with eight (138 VGPRs: a wave per SIMD
+// less), no change at C5: the lanes' own loads are not what the kernel waits for, and the LDS round trip and its index arithmetic
+// come on top of the memory one.)
 // One slot of a long run (added by the whole wave, lanes striding over the run).  The validity byte is awaited before the record is
 // requested: asking for both at once -- the record of an invalid slot is readable garbage -- saves a round trip per 64 slots and
 // was measured in round 4: per-Gaussian backward 0.120 -> 0.129 ms at C3, 0.63 -> 0.80 at C5 (the records of the invalid slots are
