@@ -143,11 +143,17 @@ typedef unsigned long long GsrSlotMask;
 __device__ __forceinline__ uint32_t gsr_slot_mask_first(unsigned long long m) { return (uint32_t)__builtin_ctzll(m | 0x8000000000000000ull); }
 #endif
 
-// (Also measured in round 4 and rejected: the wave's 64 runs -- contiguous in memory with the slots in index order -- read as one flat
-// stream of 16-byte loads into LDS, nine words per record, every lane then adding its own records from there in the same order.
-// Bit-identical results; 0.124 -> 0.184 ms at C3 with four loads in flight per lane, 0.207 with eight (138 VGPRs: a wave per SIMD
-// less), no change at C5: the lanes' own loads are not what the kernel waits for, and the LDS round trip and its index arithmetic
-// come on top of the memory one.)
+// Measured in round 4 and rejected, all with bit-identical results:
+// * the wave's 64 runs -- contiguous in memory with the slots in index order -- read as one flat stream of 16-byte loads into LDS,
+//   nine words per record, every lane then adding its own records from there in the same order: 0.124 -> 0.184 ms at C3 with four
+//   loads in flight per lane, 0.207 with eight (138 VGPRs: a wave per SIMD less), no change at C5 -- the LDS round trip and its
+//   index arithmetic come on top of the memory one;
+// * the chunks of ALL the wave's long runs taken four at a time, validity bytes requested together, then the records together (two
+//   round trips per batch instead of two per chunk; nine waves in ten hold long runs at C3, 2.7 each): 0.119 -> 0.123 ms at C3,
+//   0.629 -> 0.631 at C5 (two at a time 0.120, eight 0.122 / 0.679) -- the chain of a wave's round trips is hidden by the other waves.
+// What the time goes to is bytes: timing-only ablations at C3 -- no slot sums at all 0.122 -> 0.076 ms, no long runs 0.103, no
+// dL/dsh block (192 of the kernel's 480 MB) 0.081, none of the other stores 0.104 -- at 4.0 TB/s of mixed reads and writes, 64 % of
+// what a copy reaches on this chip.
 // One slot of a long run (added by the whole wave, lanes striding over the run).  The validity byte is awaited before the record is
 // requested: asking for both at once -- the record of an invalid slot is readable garbage -- saves a round trip per 64 slots and
 // was measured in round 4: per-Gaussian backward 0.120 -> 0.129 ms at C3, 0.63 -> 0.80 at C5 (the records of the invalid slots are
