@@ -210,6 +210,7 @@ extern "C" int gsr_geometry_layout_of(int P, gsr_geometry_layout* o)
 	o->scan_temp = off;      off = gsr_align_up(off + 2 * gsr_align_up(nb * 4));   // depth-ordered block sums, then the preprocess workgroups' tile counts
 	o->sort_table = off;     off = gsr_align_up(off + gsr_radix_table_bytes(n));
 	o->col_table = off;      off = gsr_align_up(off + gsr_tilebin_col_table_bytes(n));
+	o->rshape = off;         off = gsr_align_up(off + n * 8);
 	o->total = off;
 	return GSR_OK;
 }
@@ -296,6 +297,7 @@ GsrGeometry gsr_geometry_view(void* blob, int P)
 	g.block_tiles = (uint32_t*)(b + l.scan_temp + gsr_align_up(((size_t)P + GSR_PREPROCESS_BLOCK - 1) / GSR_PREPROCESS_BLOCK * 4));
 	g.sort_table = (void*)(b + l.sort_table);
 	g.col_table = (void*)(b + l.col_table);
+	g.rshape = (uint2*)(b + l.rshape);
 	return g;
 }
 
@@ -468,6 +470,7 @@ static int gsr_forward_preprocess_impl(int P, int D, int M, int width, int heigh
 	// when every stage is being timed, with GSR_DEBUG_SYNC (a device sync follows every stage) and with GSR_DEBUG_SERIAL.
 	GsrThreadDevice& td = g_thread.dev[device];
 	const bool col_pairs = gsr_tilebin_applies(width, height) && !(debug & GSR_DEBUG_TILE_SORT);   // (stage 2 decides the same way)
+	a.trim = (col_pairs && !(debug & GSR_DEBUG_NO_TRIM)) ? 1 : 0;   // tiles a splat provably misses are left out of the column-pair binning (gsr_rect_trim.h); the tile sort bins them all
 	const bool color = gsr_preprocess_needs_color(a);
 	// Depth order: up to GSR_BUCKET_SORT_MAX_P Gaussians in three launches whatever the depth range (depthsort.hip: top-digit buckets,
 	// then every bucket sorted inside LDS; the result lands in (depth_keys, perm) and the rectangles in depth order come with it).

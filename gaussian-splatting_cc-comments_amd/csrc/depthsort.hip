@@ -586,7 +586,7 @@ void gsr_launch_depth_bucket_sort(GsrGeometry g, int P, uint4* seg, hipStream_t 
 {
 	const uint32_t* bias = g.status + GSR_STATUS_NEGMIN;
 	uint4* recs = gsr_tilebin_recs(g, P);   // level 1's records {tile rectangle, id, -} in bucket order
-	gsr_radix_top_pass(g.depth_keys, g.depth_keys_alt, g.rect, recs, (size_t)P, g.sort_table, bias, s, g.slot_base, g.block_tiles, g.status);
+	gsr_radix_top_pass(g.depth_keys, g.depth_keys_alt, g.rshape, recs, (size_t)P, g.sort_table, bias, s, g.slot_base, g.block_tiles, g.status);
 	// what the chip holds at once (three workgroups per CU: LDS), each taking items in turn; fewer when there cannot be that many items
 	const size_t items_max = 2 * ((size_t)P / DS_PART_TARGET) + 256;
 	const unsigned grid = (unsigned)(items_max < 256 * DS_GRID_PER_CU ? items_max : 256 * DS_GRID_PER_CU);

@@ -34,6 +34,7 @@ struct GsrGeometry {
 	uint32_t* perm_alt;
 	uint32_t* tiles_touched;
 	uint2* rect;               // dense copy of the tile rectangle {x | y << 16, w | h << 16}: what the depth-ordered kernels gather
+	uint2* rshape;             // {rectangle in one word, trim word} (gsr_rect_trim.h): what the depth sort carries along and the column-pair binning reads
 	uint32_t* slot_base;       // first (Gaussian,tile) gradient slot: exclusive prefix of tiles_touched in index order (status word 3) or in depth order
 	uint8_t* clamped;
 	float* sh_ddir;            // [9][P] d(colour channel c)/d(unit view direction) of the visible Gaussians (plane 3c + {x,y,z})
@@ -108,6 +109,7 @@ struct GsrPreprocessArgs {
 	const float* cam_pos;
 	float tan_fovx, tan_fovy, focal_x, focal_y;
 	int prefiltered;
+	int trim;   // 0: GSR_DEBUG_NO_TRIM
 	int* radii;
 	GsrGeometry g;
 	// leaf mode (gsr_forward_preprocess_leaf): shs = _features_dc, shs_rest = _features_rest,

@@ -1,0 +1,121 @@
+// gsr_rect_trim.h -- which tiles of its rectangle a Gaussian can reach at all, and how the binning is told.
+//
+// The reference bins a Gaussian into every tile of the square of 3 sigma (radius rounded up) around its centre
+// (getRect, auxiliary.h:42-58; duplicateWithKeys, rasterizer_impl.cu:78-126), and the blend loops then find, pixel by pixel, that
+// most of those tiles hold no pixel with alpha >= 1 / 255 (forward.cu:449-456, backward.cu:527-534): the splat is an ellipse, its
+// opacity lowers the threshold, and the square is rounded up to tiles.  At 1 M Gaussians / 1080p 9.2 M instances are binned and 53 %
+// of them can contribute somewhere in their tile.  An instance that contributes to no pixel of its tile changes nothing: not the
+// pixels' T or colour, not n_contrib's meaning for the backward (the position of the last contributor in the list the backward walks
+// -- the same list), no gradient.  So the column-pair binning (tilebin.hip) leaves out tiles that the ellipse
+//     conic_a dx^2 + 2 conic_b dx dy + conic_c dy^2 <= 2 ln(255 opacity)            (alpha >= 1 / 255  <=>  power >= -ln(255 opacity))
+// provably misses, per tile COLUMN of the rectangle: up to three tile rows off the top and up to three off the bottom of every
+// column (two bits each: a nibble per column, eight columns in one word), empty columns off the left and right edge.  Rectangles wider
+// than eight tiles are binned whole.  What is kept is a superset of what can contribute (the bound is taken over the column's whole
+// strip of pixel centres, with margins far above the fp32 error of `power` and of exp), so every output -- image, radii, gradients --
+// has the same bits with and without it (GSR_DEBUG_NO_TRIM; tests/test_trim_gpu.py, tools/determinism_stress.py), and the slots of
+// the left-out instances are exactly slots the backward never marks valid.  num_rendered, tiles_touched and the gradient slots keep
+// the reference's numbering over the WHOLE rectangle; point_list and the tile ranges are the reference's with the left-out instances
+// removed (the reference's own, bit for bit, with GSR_DEBUG_NO_TRIM and on the tile-sort path).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+// the rectangle in one word (tile coordinates < 256, sizes 1 .. 256); no tiles: GSR_RECT_NONE
+#define GSR_RECT_NONE 0xFFFFFFFFu
+__host__ __device__ __forceinline__ uint32_t gsr_rect_pack(uint32_t x0, uint32_t y0, uint32_t w, uint32_t h)
+{
+	return (w == 0u || h == 0u) ? GSR_RECT_NONE : (x0 | (y0 << 8) | ((w - 1u) << 16) | ((h - 1u) << 24));
+}
+__host__ __device__ __forceinline__ void gsr_rect_unpack(uint32_t r, uint32_t& x0, uint32_t& y0, uint32_t& w, uint32_t& h)
+{
+	if (r == GSR_RECT_NONE) { x0 = y0 = w = h = 0u; return; }
+	x0 = r & 0xffu; y0 = (r >> 8) & 0xffu; w = ((r >> 16) & 0xffu) + 1u; h = (r >> 24) + 1u;
+}
+
+#define GSR_TRIM_MAX_COLUMNS 8   // columns a trim word describes
+#define GSR_TRIM_MAX_ROWS 3      // rows it can take off either end of a column
+
+// rows taken off column c of a rectangle (c < 8 for a non-zero word; a wider rectangle's word is 0): top (small y), bottom
+__host__ __device__ __forceinline__ void gsr_trim_of(uint32_t trim, uint32_t c, uint32_t& top, uint32_t& bottom)
+{
+	const uint32_t nib = c < (uint32_t)GSR_TRIM_MAX_COLUMNS ? (trim >> (4u * c)) & 15u : 0u;
+	top = nib & 3u;
+	bottom = nib >> 2;
+}
+
+// the columns of a w x h rectangle that keep at least one row: [lead, lead + wt).  (The producer leaves no empty column between two
+// kept ones -- gsr_rect_trim -- so that the kept columns are one run: the binning's histograms are difference arrays.)
+__host__ __device__ __forceinline__ void gsr_trim_columns(uint32_t trim, uint32_t w, uint32_t h, uint32_t& lead, uint32_t& wt)
+{
+	lead = 0u; wt = w;
+	if (trim == 0u || w > (uint32_t)GSR_TRIM_MAX_COLUMNS) return;
+	uint32_t first = w, last = 0u;
+#pragma unroll
+	for (uint32_t c = 0; c < (uint32_t)GSR_TRIM_MAX_COLUMNS; c++) {
+		uint32_t t, b;
+		gsr_trim_of(trim, c, t, b);
+		if (c < w && t + b < h) { first = first < c ? first : c; last = c + 1u; }
+	}
+	if (first >= last) { lead = 0u; wt = 0u; return; }
+	lead = first; wt = last - first;
+}
+
+#ifdef __HIPCC__
+// The trim word of one Gaussian: centre (px, py) in pixel coordinates, conic (ca, cb, cc) and opacity as the blend kernels will read
+// them from its record, rectangle [x0, x0 + w) x [y0, y0 + h) in tiles.  0 = nothing is taken off.
+__device__ __forceinline__ uint32_t gsr_rect_trim(float px, float py, float ca, float cb, float cc, float opacity, int x0, int y0, int w, int h)
+{
+	if (w > GSR_TRIM_MAX_COLUMNS || w <= 0 || h <= 0) return 0u;
+	const float det = ca * cc - cb * cb;
+	// q = ca dx^2 + 2 cb dx dy + cc dy^2 <= tau is necessary for alpha >= 1 / 255; the margin (0.1 % + 0.01) is thousands of times the
+	// error of the kernels' fp32 `power` and exp at these magnitudes (tau <= 11.1)
+	const float tau = 2.0f * __logf(255.0f * opacity) * 1.001f + 0.01f;
+	if (!(det > 0.0f) || !(ca > 0.0f) || !(cc > 0.0f) || !(tau == tau)) return 0u;   // not an ellipse this bound understands: keep everything
+	uint32_t trim = 0u;
+	uint32_t first = (uint32_t)w, last = 0u;
+	if (tau > 0.0f) {
+		const float ex = sqrtf(tau * cc / det) * 1.0001f + 0.01f;      // half width of the ellipse
+		const float eyy = sqrtf(tau * ca / det) * 1.0001f + 0.01f;     // half height
+		const float xs = -cb * sqrtf(tau / (det * ca));                // dx of the ellipse's bottom point (largest dy); its top point: -xs
+		const float inv_cc = 1.0f / cc;
+#pragma unroll
+		for (int c = 0; c < GSR_TRIM_MAX_COLUMNS; c++) {
+			if (c >= w) break;
+			// the strip of pixel centres of tile column x0 + c, relative to the centre, widened by the margin
+			float lo = (float)((x0 + c) * GSR_TILE_X) - px - 0.01f, hi = (float)((x0 + c) * GSR_TILE_X + (GSR_TILE_X - 1)) - px + 0.01f;
+			uint32_t t = GSR_TRIM_MAX_ROWS, b = GSR_TRIM_MAX_ROWS;   // the ellipse misses the strip: as much off as the word can say
+			if (lo <= ex && hi >= -ex) {
+				lo = fmaxf(lo, -ex); hi = fminf(hi, ex);
+				// largest dy over the strip: the ellipse's bottom point if its dx lies inside, else at the nearer end (the boundary is concave)
+				const float rlo = sqrtf(fmaxf(0.0f, tau * cc - det * lo * lo)), rhi = sqrtf(fmaxf(0.0f, tau * cc - det * hi * hi));
+				float ymax = fmaxf((-cb * lo + rlo) * inv_cc, (-cb * hi + rhi) * inv_cc);
+				float ymin = fminf((-cb * lo - rlo) * inv_cc, (-cb * hi - rhi) * inv_cc);
+				if (lo <= xs && xs <= hi) ymax = eyy;
+				if (lo <= -xs && -xs <= hi) ymin = -eyy;
+				ymax = ymax * 1.0001f + 0.01f;
+				ymin = ymin * 1.0001f - 0.01f;
+				// tile rows that hold a pixel centre in [py + ymin, py + ymax] -- or fewer: rows of the bounds themselves
+				const float r0 = floorf((py + ymin) * (1.0f / GSR_TILE_Y)), r1 = floorf((py + ymax) * (1.0f / GSR_TILE_Y));
+				const float tf = fminf(fmaxf(r0 - (float)y0, 0.0f), (float)GSR_TRIM_MAX_ROWS);
+				const float bf = fminf(fmaxf((float)(y0 + h - 1) - r1, 0.0f), (float)GSR_TRIM_MAX_ROWS);
+				t = (uint32_t)tf; b = (uint32_t)bf;
+			}
+			trim |= (t | (b << 2)) << (4 * c);
+			if (t + b < (uint32_t)h) { first = first < (uint32_t)c ? first : (uint32_t)c; last = (uint32_t)c + 1u; }
+		}
+	} else {
+		// opacity below 1 / 255 (with the margin): alpha >= 1 / 255 nowhere
+#pragma unroll
+		for (int c = 0; c < GSR_TRIM_MAX_COLUMNS; c++)
+			if (c < w) trim |= 15u << (4 * c);
+	}
+	// no empty column between two kept ones (cannot happen for a convex shape; the decoder relies on it): give such a column back whole
+#pragma unroll
+	for (int c = 0; c < GSR_TRIM_MAX_COLUMNS; c++)
+		if ((uint32_t)c > first && (uint32_t)c + 1u < last) {
+			const uint32_t nib = (trim >> (4 * c)) & 15u;
+			if ((nib & 3u) + (nib >> 2) >= (uint32_t)h) trim &= ~(15u << (4 * c));
+		}
+	return trim;
+}
+#endif

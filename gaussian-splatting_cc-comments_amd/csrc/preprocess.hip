@@ -7,6 +7,7 @@
 // partial counters -- so no scan over P follows.
 #include "gsr_internal.h"
 #include <hip/hip_ext.h>
+#include "gsr_rect_trim.h"
 
 // forward.cu:21-81 computeColorFromSH, one channel at a time in the glm::vec3 expression order
 __device__ __forceinline__ float gsr_sh_channel(int deg, const float* sh, int ch, float x, float y, float z)
@@ -66,6 +67,7 @@ __global__ void __launch_bounds__(GSR_PREPROCESS_BLOCK) gsr_preprocess_kernel(Gs
 	}
 	uint32_t tiles = 0;
 	uint2 rect = make_uint2(0u, 0u);
+	uint2 rshape = make_uint2(GSR_RECT_NONE, 0u);   // {rectangle in one word, trim word}: what the binning reads (gsr_rect_trim.h)
 	int radius_out = 0;
 	uint32_t depth_key = 0xFFFFFFFFu;  // culled Gaussians sort behind every visible one
 	const int gx = (a.W + GSR_TILE_X - 1) / GSR_TILE_X, gy = (a.H + GSR_TILE_Y - 1) / GSR_TILE_Y;
@@ -119,7 +121,10 @@ __global__ void __launch_bounds__(GSR_PREPROCESS_BLOCK) gsr_preprocess_kernel(Gs
 			// the geometry part of the record (GsrSplat: x, y, conic a, b | conic c, opacity, rect | colour): two 16-byte stores, 32 contiguous bytes
 			float4* rec = reinterpret_cast<float4*>(a.g.splat + idx);
 			rec[0] = make_float4(pix, piy, conic_a, conic_b);
-			rec[1] = make_float4(conic_c, LEAF ? gsr_act_sigmoid(opac) : opac, __uint_as_float(rect.x), __uint_as_float(rect.y));
+			const float opacity = LEAF ? gsr_act_sigmoid(opac) : opac;
+			rec[1] = make_float4(conic_c, opacity, __uint_as_float(rect.x), __uint_as_float(rect.y));
+			rshape.x = gsr_rect_pack((uint32_t)minx, (uint32_t)miny, (uint32_t)(maxx - minx), (uint32_t)(maxy - miny));
+			if (a.trim) rshape.y = gsr_rect_trim(pix, piy, conic_a, conic_b, conic_c, opacity, minx, miny, maxx - minx, maxy - miny);
 			if (a.colors_precomp) {
 				rec[2] = make_float4(col_in[0], col_in[1], col_in[2], 0.f);
 				a.g.clamped[idx] = 0;
@@ -128,6 +133,7 @@ __global__ void __launch_bounds__(GSR_PREPROCESS_BLOCK) gsr_preprocess_kernel(Gs
 		if (a.radii) a.radii[idx] = radius_out;  // optional, cuda_rasterizer/rasterizer.h:52
 		a.g.tiles_touched[idx] = tiles;
 		a.g.rect[idx] = rect;             // dense copy: the depth-ordered kernels gather 8 bytes, not a 48-byte record
+		a.g.rshape[idx] = rshape;
 		a.g.depth_keys[idx] = depth_key;  // inputs of the depth sort (sort.hip)
 		a.g.perm[idx] = (uint32_t)idx;
 	}

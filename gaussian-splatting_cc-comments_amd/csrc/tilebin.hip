@@ -36,6 +36,7 @@
 // trips per group instead of ten per round, but the loops run to the longest segment of the wave: 0.055 -> 0.084 ms).
 #include "gsr_internal.h"
 #include "gsr_radix_walk.h"
+#include "gsr_rect_trim.h"
 
 #define TB_THREADS 256
 #define TB_WAVES (TB_THREADS / 64)
@@ -123,37 +124,42 @@ __device__ __forceinline__ void tb_wave_bases(uint32_t (*wcount)[TB_RADIX], uint
 // its payloads.  Pass 2 packs it into 8 bytes (one ds_read_b64 per element), pass 1 carries a 16-bit key as well.
 struct TbOwnRow {
 	uint2 v;
-	static __device__ TbOwnRow make(uint32_t start, uint32_t d0, uint32_t, uint32_t b) { TbOwnRow o; o.v = make_uint2(start | (d0 << 16), b); return o; }
+	static __device__ TbOwnRow make(uint32_t start, uint32_t d0, uint32_t, uint32_t b, uint32_t = 0u) { TbOwnRow o; o.v = make_uint2(start | (d0 << 16), b); return o; }
 	__device__ uint32_t start() const { return v.x & 0xffffu; }
 	__device__ uint32_t d0() const { return v.x >> 16; }
 	__device__ uint32_t a() const { return 0u; }
 	__device__ uint32_t b() const { return v.y; }
+	__device__ uint32_t c() const { return 0u; }
 };
+// pass 1: a = the column's rows before trimming (y0 | (h - 1) << 8) with the number of the rectangle's first kept column in bits 16..18,
+// b = Gaussian id, c = the rectangle's trim word (gsr_rect_trim.h)
 struct TbOwnCol {
 	uint4 v;
-	static __device__ TbOwnCol make(uint32_t start, uint32_t d0, uint32_t a, uint32_t b) { TbOwnCol o; o.v = make_uint4(start, d0, a, b); return o; }
-	__device__ uint32_t start() const { return v.x; }
-	__device__ uint32_t d0() const { return v.y; }
-	__device__ uint32_t a() const { return v.z; }
-	__device__ uint32_t b() const { return v.w; }
+	static __device__ TbOwnCol make(uint32_t start, uint32_t d0, uint32_t a, uint32_t b, uint32_t c = 0u) { TbOwnCol o; o.v = make_uint4(start | (d0 << 16), a, b, c); return o; }
+	__device__ uint32_t start() const { return v.x & 0xffffu; }
+	__device__ uint32_t d0() const { return v.x >> 16; }
+	__device__ uint32_t a() const { return v.y; }
+	__device__ uint32_t b() const { return v.z; }
+	__device__ uint32_t c() const { return v.w; }
 };
 
 // One group of 64 segments of a wave, expanded 64 elements per round and ranked by digit.  Lane l holds segment l: first
-// digit d0 (< 256), length len (0 = none, <= 256), payloads a, b.  For every generated element: store(position, a, b) with
+// digit d0 (< 256), length len (0 = none, <= 256), payloads a, b, c.  For every generated element: store(position, its segment's record, its
+// number inside the segment) with
 // position = the wave's running count of the element's digit (mycount[d], initialised to the global position of the wave's first
 // element of digit d) -- stable: elements of one digit leave in generation order.
 //   s_own[64], s_flag[64]: this wave's (s_flag zero before the wave's first call); round: the wave's round counter -- it tags
 //   the head flags, so that s_flag needs no clearing between rounds; mymask: this wave's TB_RADIX 64-bit words, all zero on
 //   entry and on exit.
 template <typename Own, typename Store>
-__device__ __forceinline__ void tb_expand_group(uint32_t d0, uint32_t len, uint32_t a, uint32_t b, Own* s_own, uint32_t* s_flag,
+__device__ __forceinline__ void tb_expand_group(uint32_t d0, uint32_t len, uint32_t a, uint32_t b, uint32_t c, Own* s_own, uint32_t* s_flag,
                                                 uint32_t& round, unsigned long long* mymask, uint32_t* mycount, Store&& store)
 {
 	const int lane = threadIdx.x & 63;
 	const uint32_t incl = tb_wave_incl_scan(len);
 	const uint32_t start = incl - len;   // < 64 * 256
 	const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-	s_own[lane] = Own::make(start, d0, a, b);
+	s_own[lane] = Own::make(start, d0, a, b, c);
 	__builtin_amdgcn_wave_barrier();
 	const unsigned long long lanebit = 1ull << lane;
 	uint32_t carry = 0u;  // lane + 1 of the segment that owns the element in front of the round
@@ -198,7 +204,7 @@ __device__ __forceinline__ void tb_expand_group(uint32_t d0, uint32_t len, uint3
 			__atomic_store_n(&mymask[d], 0ull, __ATOMIC_RELAXED);
 		}
 		__builtin_amdgcn_wave_barrier();
-		if (valid) store(old + below, own.a(), own.b());
+		if (valid) store(old + below, own, j - own.start());
 	}
 	__builtin_amdgcn_wave_barrier();  // s_own is rewritten by the next group
 }
@@ -234,12 +240,12 @@ __global__ void __launch_bounds__(TB_THREADS) gsr_tb_col_hist_kernel(const uint3
 				id[q] = i < P ? perm[i] : 0xFFFFFFFFu;
 			}
 #pragma unroll
-			for (int q = 0; q < TB_GROUPS; q++) rc[q] = id[q] != 0xFFFFFFFFu ? rect[id[q]] : make_uint2(0u, 0u);
+			for (int q = 0; q < TB_GROUPS; q++) rc[q] = id[q] != 0xFFFFFFFFu ? rect[id[q]] : make_uint2(GSR_RECT_NONE, 0u);
 		} else {   // the bucket depth sort (depthsort.hip) left the rectangles in depth order already: one coalesced load
 #pragma unroll
 			for (int q = 0; q < TB_GROUPS; q++) {
 				const int i = block * TB_BLOCK + wave * (64 * TB_GROUPS) + q * 64 + lane;
-				const uint4 sg = i < P ? seg[i] : make_uint4(0u, 0u, 0xFFFFFFFFu, 0u);
+				const uint4 sg = i < P ? seg[i] : make_uint4(GSR_RECT_NONE, 0u, 0xFFFFFFFFu, 0u);
 				rc[q] = make_uint2(sg.x, sg.y);
 				id[q] = sg.z;
 			}
@@ -249,14 +255,15 @@ __global__ void __launch_bounds__(TB_THREADS) gsr_tb_col_hist_kernel(const uint3
 #pragma unroll
 		for (int q = 0; q < TB_GROUPS; q++) {
 			const int i = block * TB_BLOCK + wave * (64 * TB_GROUPS) + q * 64 + lane;
-			const uint32_t w = rc[q].y & 0xffffu, h = rc[q].y >> 16;
+			uint32_t x0, y0, w, h, lead, wt;
+			gsr_rect_unpack(rc[q].x, x0, y0, w, h);
+			gsr_trim_columns(rc[q].y, w, h, lead, wt);   // the columns that keep a row: [x0 + lead, x0 + lead + wt)
 			if (perm && i < P) seg[i] = make_uint4(rc[q].x, rc[q].y, id[q], 0u);
-			if (w * h) {
-				const uint32_t x0 = rc[q].x & 0xffffu;
-				atomicAdd(&diff[x0], 1);
-				atomicAdd(&diff[x0 + w], -1);
-				tiles += w * h;
+			if (wt) {
+				atomicAdd(&diff[x0 + lead], 1);
+				atomicAdd(&diff[x0 + lead + wt], -1);
 			}
+			tiles += w * h;   // (the gradient slots are numbered over the whole rectangle)
 		}
 		__syncthreads();
 		// difference array (+1 at the first column, -1 behind the last) -> prefix sum over the digits = pairs per column
@@ -333,17 +340,20 @@ __global__ void __launch_bounds__(TB_THREADS) gsr_tb_col_scatter_kernel(const ui
 #pragma unroll
 		for (int q = 0; q < TB_GROUPS; q++) {
 			const int i = blk * TB_BLOCK + wave * (64 * TB_GROUPS) + q * 64 + lane;
-			sg[q] = i < P ? seg[i] : make_uint4(0u, 0u, 0u, 0u);
+			sg[q] = i < P ? seg[i] : make_uint4(GSR_RECT_NONE, 0u, 0u, 0u);
 		}
-		uint32_t id[TB_GROUPS], d0[TB_GROUPS], len[TB_GROUPS], key[TB_GROUPS], tiles[TB_GROUPS], incl_t[TB_GROUPS];
+		uint32_t id[TB_GROUPS], d0[TB_GROUPS], len[TB_GROUPS], key[TB_GROUPS], trim[TB_GROUPS], tiles[TB_GROUPS], incl_t[TB_GROUPS];
 #pragma unroll
 		for (int q = 0; q < TB_GROUPS; q++) {
-			const uint32_t w = sg[q].y & 0xffffu, h = sg[q].y >> 16;
+			uint32_t x0, y0, w, h, lead, wt;
+			gsr_rect_unpack(sg[q].x, x0, y0, w, h);
+			gsr_trim_columns(sg[q].y, w, h, lead, wt);
 			id[q] = sg[q].z;
 			tiles[q] = w * h;
-			len[q] = tiles[q] ? w : 0u;
-			d0[q] = sg[q].x & 0xffffu;
-			key[q] = (sg[q].x >> 16) | ((h - 1u) << 8);
+			len[q] = wt;              // one element per column that keeps a row
+			d0[q] = x0 + lead;
+			trim[q] = sg[q].y;
+			key[q] = y0 | ((h - 1u) << 8) | (lead << 16);
 			incl_t[q] = tb_wave_incl_scan(tiles[q]);
 			if (lane == 63) gsum[wave * TB_GROUPS + q] = incl_t[q];
 		}
@@ -363,9 +373,14 @@ __global__ void __launch_bounds__(TB_THREADS) gsr_tb_col_scatter_kernel(const ui
 		__syncthreads();
 #pragma unroll 1
 		for (int q = 0; q < TB_GROUPS; q++)
-			tb_expand_group(d0[q], len[q], key[q], id[q], s_own[wave], s_flag[wave], round, s_mask[wave], wcount[wave],
-			                [&](uint32_t pos, uint32_t a, uint32_t b) {
-				                if (pos < capacity) cpair[pos] = make_uint2(a, b);   // always true for consistent tables; a corrupted table must not turn into a wild store
+			tb_expand_group(d0[q], len[q], key[q], id[q], trim[q], s_own[wave], s_flag[wave], round, s_mask[wave], wcount[wave],
+			                [&](uint32_t pos, const TbOwnCol& own, uint32_t e) {
+				                // the rows this column keeps: its rectangle's, less what the trim word takes off its top and bottom
+				                uint32_t t, b;
+				                gsr_trim_of(own.c(), (own.a() >> 16) + e, t, b);
+				                if (t + b > ((own.a() >> 8) & 0xffu)) t = b = 0u;   // (an empty column between kept ones: the producer leaves none; whole if it did)
+				                const uint32_t rows = (own.a() & 0xffffu) + t - ((t + b) << 8);   // (y0 + t) | (h - t - b - 1) << 8
+				                if (pos < capacity) cpair[pos] = make_uint2(rows, own.b());   // always true for consistent tables; a corrupted table must not turn into a wild store
 			                });
 		__syncthreads();   // every LDS array is rewritten by the next block
 	}
@@ -514,9 +529,9 @@ __global__ void __launch_bounds__(TB_THREADS) gsr_tb_row_scatter_kernel(const ui
 		__syncthreads();
 #pragma unroll 1
 		for (int q = 0; q < TB_GROUPS; q++)
-			tb_expand_group(d0[q], len[q], 0u, id[q], s_own[wave], s_flag[wave], round, s_mask[wave], wcount[wave],
-			                [&](uint32_t pos, uint32_t, uint32_t b) {
-				                if (pos < R) point_list[pos] = b;
+			tb_expand_group(d0[q], len[q], 0u, id[q], 0u, s_own[wave], s_flag[wave], round, s_mask[wave], wcount[wave],
+			                [&](uint32_t pos, const TbOwnRow& own, uint32_t) {
+				                if (pos < R) point_list[pos] = own.b();
 			                });
 		__syncthreads();   // every LDS array is rewritten by the next round
 	}
@@ -547,7 +562,7 @@ void gsr_launch_tilebin_col_hist(GsrGeometry g, int P, int result_in_alt, hipStr
 	int per = 1;   // consecutive blocks per workgroup: 1 up to 2 048 blocks, then as many as keep >= 1 024 workgroups
 	while (per < GSR_SORT_CHUNK && t.nblocks / (2 * per) >= 1024) per *= 2;
 	const uint32_t* perm = seg_ready ? nullptr : (result_in_alt ? g.perm_alt : g.perm);
-	hipLaunchKernelGGL(gsr_tb_col_hist_kernel, dim3((t.nblocks + per - 1) / per), dim3(TB_THREADS), 0, s, perm, g.rect, P,
+	hipLaunchKernelGGL(gsr_tb_col_hist_kernel, dim3((t.nblocks + per - 1) / per), dim3(TB_THREADS), 0, s, perm, g.rshape, P,
 	                   g.sorted_block_sums, t.table, t.nblocks, t.chunk_sums, t.nchunks, t.seg, g.status, (uint32_t)result_in_alt, per);
 }
 

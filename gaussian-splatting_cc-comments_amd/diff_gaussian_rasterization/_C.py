@@ -27,7 +27,7 @@ _sz = ctypes.c_size_t
 
 class GeometryLayout(ctypes.Structure):
     _fields_ = [(n, _sz) for n in ("splat", "depth_keys", "depth_keys_alt", "perm", "perm_alt", "tiles_touched", "rect",
-                                   "slot_base", "clamped", "sh_ddir", "status", "scan_temp", "sort_table", "col_table", "total")]
+                                   "slot_base", "clamped", "sh_ddir", "status", "scan_temp", "sort_table", "col_table", "rshape", "total")]
 
 
 class ImageLayout(ctypes.Structure):
@@ -58,7 +58,7 @@ class BackwardArgs(ctypes.Structure):
 
 # bits of the C ABI's `debug` mask (include/gsr.h GSR_DEBUG_*).  The reference's bool `debug` is DEBUG_SYNC; tests pass the
 # diagnostic bits as an int in the same argument, per call -- nothing is read from the environment.
-DEBUG_SYNC, DEBUG_NO_CULL, DEBUG_SERIAL, DEBUG_NO_SPLIT, DEBUG_TILE_SORT, DEBUG_RADIX_DEPTH = 1, 2, 4, 8, 16, 32
+DEBUG_SYNC, DEBUG_NO_CULL, DEBUG_SERIAL, DEBUG_NO_SPLIT, DEBUG_TILE_SORT, DEBUG_RADIX_DEPTH, DEBUG_NO_TRIM = 1, 2, 4, 8, 16, 32, 64
 
 
 def _dbg(debug):

@@ -50,6 +50,9 @@ typedef enum {
                                  binned by column pairs; same point_list, same ranges */
 #define GSR_DEBUG_RADIX_DEPTH 32 /* gsr_forward_preprocess*: the Gaussians are put in depth order by three or four global radix passes (the path
                                   of more than 2 Mi Gaussians) instead of top-digit buckets sorted inside LDS; same order */
+#define GSR_DEBUG_NO_TRIM 64 /* gsr_forward_preprocess*: every tile of a Gaussian's rectangle is binned, like the reference does; default: tiles that
+                                the splat's ellipse at alpha = 1 / 255 provably misses are left out of point_list (csrc/gsr_rect_trim.h: same
+                                image, radii, gradients and num_rendered, bit for bit; shorter tile lists) */
 #define GSR_DEBUG_NO_SPLIT 8 /* gsr_forward_render: heavy tiles (instance lists >= 1024 and >= 2x the mean) are blended by one wave like
                                 every other tile, not by four waves of one 16x4-pixel band each (same results either way) */
 
@@ -95,6 +98,9 @@ typedef struct {
 	size_t sort_table;     /* radix histogram table of the depth sort */
 	size_t col_table;      /* column-pair binning, pass 1 (by tile column): chunk sums, per-workgroup digit rows, 256 digit totals, the
 	                          Gaussians' {rectangle, id} records in depth order and (bucket depth sort) in bucket order, 16 B each */
+	size_t rshape;         /* [P] uint2 {rectangle in one word: x | y << 8 | (w - 1) << 16 | (h - 1) << 24, 0xFFFFFFFF = no tiles; trim word:
+	                          a nibble per tile column of the rectangle, rows left out at its top (2 bits) and bottom (2 bits)}: what the
+	                          column-pair binning reads (csrc/gsr_rect_trim.h) */
 	size_t total;
 } gsr_geometry_layout;
 

@@ -99,11 +99,17 @@ def test_bucket_sort_and_radix_sort_give_the_stable_argsort(name):
         ts = tt[want]
         np.testing.assert_array_equal(b["slot_base"][want][ts > 0], (np.cumsum(ts) - ts)[ts > 0].astype(np.uint32))
     # ... and the same through the instance emission + tile sort, which reads the depth order through perm and the block sums
+    # (it bins every tile of every rectangle, like the reference: compared with the column pairs doing the same, GSR_DEBUG_NO_TRIM;
+    # the image is the default run's bit for bit either way)
     c = _run(scene, cam, 0, _C.DEBUG_TILE_SORT)
+    a0 = _run(scene, cam, 0, _C.DEBUG_NO_TRIM)
     np.testing.assert_array_equal(c["perm"], want)
+    np.testing.assert_array_equal(c["color"], a["color"])
+    np.testing.assert_array_equal(a0["color"], a["color"])
     if a["R"] > 0:
-        np.testing.assert_array_equal(c["point_list"], a["point_list"])
-        np.testing.assert_array_equal(c["ranges"], a["ranges"])
+        np.testing.assert_array_equal(c["point_list"], a0["point_list"])
+        np.testing.assert_array_equal(c["ranges"], a0["ranges"])
+        assert len(a["point_list"]) <= len(a0["point_list"]) == a["R"]
     print(f"{name}: P {P}, visible {visible}, distinct keys {len(np.unique(bits))}, R {a['R']}")
 
 

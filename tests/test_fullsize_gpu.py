@@ -76,10 +76,17 @@ def _full_parity(name):
     scene, cam, D = gsr_scene.make_config(name)
     o = util.oracle_forward(scene, cam, D)
     dpix = util.fragile_free_dpix(o, cam)
+    from diff_gaussian_rasterization import _C
     h = util.hip_forward_backward(scene, cam, D, dpix)
     err = check_forward(h, o, cam)
+    # ... and with every tile of every rectangle binned (GSR_DEBUG_NO_TRIM): the reference's own lists, and the same image bit for bit
+    h0 = util.hip_forward_backward(scene, cam, D, None, debug=_C.DEBUG_NO_TRIM)
+    check_forward(h0, o, cam)
+    assert len(h0["point_list"]) == o["num_rendered"] and np.array_equal(h0["color"], h["color"]) and np.array_equal(h0["final_T"], h["final_T"])
     util.parity_log(f"[{name}] P={o['P']} {cam.image_width}x{cam.image_height} deg {D}: R={o['num_rendered']}, radii / tiles / "
-                    f"point_list / keys / ranges / n_contrib exact, image max-abs (non-fragile) {err:.3e}")
+                    f"point_list / keys / ranges / n_contrib exact (binning every tile: the oracle's lists; default: the oracle's lists less the "
+                    f"{o['num_rendered'] - len(h['point_list'])} instances the trim words name, {len(h['point_list'])} listed), image identical in both, "
+                    f"max-abs (non-fragile) {err:.3e}")
     check_grads(h, o, dpix, NAMES, label=name)
     return scene, cam, D, o, h
 
@@ -169,38 +176,12 @@ def test_c4_eight_views_summed_gradients_match_oracle(tmp_path):
     assert not bad, "\n".join(lines)
 
 
-def _properties(name, check_linearity=True):
-    from diff_gaussian_rasterization import GaussianRasterizer, _C
-    dev = torch.device("cuda:0")
-    scene, cam, D = gsr_scene.make_config(name)
-    P, W, H = scene.means3D.shape[0], cam.image_width, cam.image_height
-    T = ((W + 15) // 16) * ((H + 15) // 16)
-    settings = util.hip_settings(scene, cam, D, dev)
-    leaves = dict(means3D=scene.means3D, shs=scene.shs, opacities=scene.opacities, scales=scene.scales,
-                  rotations=scene.rotations)
-    g = torch.Generator().manual_seed(2)
-    dpix = torch.randn(3, H, W, generator=g).to(dev)
-
-    def run(scale):
-        p = {k: v.to(dev).clone().requires_grad_(True) for k, v in leaves.items()}
-        means2D = torch.zeros_like(p["means3D"], requires_grad=True)
-        cap = {}
-        orig = _C.rasterize_gaussians
-
-        def spy(*a):
-            r = orig(*a)
-            cap["R"], cap["geom"], cap["binning"], cap["img"] = r[0], r[3], r[4], r[5]
-            return r
-        _C.rasterize_gaussians = spy
-        try:
-            color, radii = GaussianRasterizer(settings)(means2D=means2D, **p)
-        finally:
-            _C.rasterize_gaussians = orig
-        color.backward(dpix * scale)
-        torch.cuda.synchronize()
-        return color.detach(), radii, {k: v.grad for k, v in p.items()}, means2D.grad, cap
-
-    color, radii, grads, g2d, cap = run(1.0)
+def _list_structure(cap, radii, P, W, H, T, dev, whole):
+    """Size-independent properties of the sorted instance list of one forward: sorted by tile, by depth inside a tile, ties in index
+    order; every instance inside its Gaussian's rectangle, no (tile, Gaussian) pair twice; the ranges partition the list.  whole:
+    the run binned every tile of every rectangle (GSR_DEBUG_NO_TRIM) -- then every rectangle tile appears exactly once and the list
+    has num_rendered entries; otherwise at most once, and fewer.  Returns the number of listed instances."""
+    from diff_gaussian_rasterization import _C
     R = cap["R"]
     gl, il, bl = _C.geometry_layout(P), _C.image_layout(W, H), _C.binning_layout(P, R, W, H)
     u32 = lambda buf, off, n: buf[off:off + 4 * n].view(torch.int32)
@@ -209,7 +190,8 @@ def _properties(name, check_linearity=True):
     assert torch.equal(tiles_touched > 0, radii > 0)
     ranges = u32(cap["img"], il.ranges, 2 * T).view(T, 2).to(torch.int64)
     lens = ranges[:, 1] - ranges[:, 0]
-    assert int(lens.sum()) == R and bool((lens >= 0).all())
+    L = int(lens.sum())
+    assert (L == R if whole else L <= R) and bool((lens >= 0).all())
     if int(bl.column_pairs):
         # column-pair binning: no per-instance keys are stored; the tile of instance i is the tile whose range holds i.  The
         # ranges must partition [0, R) in tile order ...
@@ -218,8 +200,8 @@ def _properties(name, check_linearity=True):
         tile_keys = torch.repeat_interleave(torch.arange(T, device=dev), lens)
     else:
         kb = int(bl.tile_key_bytes)
-        tile_keys = cap["binning"][bl.tile_keys:bl.tile_keys + kb * R].view(torch.int16 if kb == 2 else torch.int32).to(torch.int64) & (0xFFFF if kb == 2 else 0xFFFFFFFF)
-    plist = u32(cap["binning"], bl.point_list, R).to(torch.int64)
+        tile_keys = cap["binning"][bl.tile_keys:bl.tile_keys + kb * L].view(torch.int16 if kb == 2 else torch.int32).to(torch.int64) & (0xFFFF if kb == 2 else 0xFFFFFFFF)
+    plist = u32(cap["binning"], bl.point_list, L).to(torch.int64)
     assert bool((tile_keys[1:] >= tile_keys[:-1]).all()), "instances sorted by tile"
     assert int(tile_keys.max()) < T
     # depth bits per Gaussian from the depth sort's outputs
@@ -249,13 +231,63 @@ def _properties(name, check_linearity=True):
     for sx, sy, sign in ((rx0, ry0, 1), (rx0 + rw, ry0, -1), (rx0, ry0 + rh, -1), (rx0 + rw, ry0 + rh, 1)):
         diff.index_add_(0, (sy[vis] * (gxt + 1) + sx[vis]), torch.full((int(vis.sum()),), sign, dtype=torch.int64, device=dev))
     cover = diff.view(gyt + 1, gxt + 1).cumsum(0).cumsum(1)[:gyt, :gxt].reshape(-1)
-    assert torch.equal(cover, lens), "per-tile instance counts differ from the rectangles' coverage"
+    assert torch.equal(cover, lens) if whole else bool((lens <= cover).all()), "per-tile instance counts differ from the rectangles' coverage"
     key2 = tile_keys * P + plist
-    assert int(torch.unique(key2).numel()) == R, "a (tile, Gaussian) pair appears twice"
+    assert int(torch.unique(key2).numel()) == L, "a (tile, Gaussian) pair appears twice"
     counts = torch.bincount(tile_keys, minlength=T)
     assert torch.equal(counts, lens)
     ne = lens > 0
     assert torch.equal(tile_keys[ranges[ne, 0]], torch.nonzero(ne).flatten())
+    return L
+
+
+def _properties(name, check_linearity=True):
+    from diff_gaussian_rasterization import GaussianRasterizer, _C
+    dev = torch.device("cuda:0")
+    scene, cam, D = gsr_scene.make_config(name)
+    P, W, H = scene.means3D.shape[0], cam.image_width, cam.image_height
+    T = ((W + 15) // 16) * ((H + 15) // 16)
+    settings = util.hip_settings(scene, cam, D, dev)
+    leaves = dict(means3D=scene.means3D, shs=scene.shs, opacities=scene.opacities, scales=scene.scales,
+                  rotations=scene.rotations)
+    g = torch.Generator().manual_seed(2)
+    dpix = torch.randn(3, H, W, generator=g).to(dev)
+
+    def run(scale, debug=0):
+        p = {k: v.to(dev).clone().requires_grad_(True) for k, v in leaves.items()}
+        means2D = torch.zeros_like(p["means3D"], requires_grad=True)
+        cap = {}
+        orig = _C.rasterize_gaussians
+
+        def spy(*a):
+            r = orig(*a)
+            cap["R"], cap["geom"], cap["binning"], cap["img"] = r[0], r[3], r[4], r[5]
+            return r
+        _C.rasterize_gaussians = spy
+        try:
+            color, radii = GaussianRasterizer(settings._replace(debug=debug) if debug else settings)(means2D=means2D, **p)
+        finally:
+            _C.rasterize_gaussians = orig
+        color.backward(dpix * scale)
+        torch.cuda.synchronize()
+        return color.detach(), radii, {k: v.grad for k, v in p.items()}, means2D.grad, cap
+
+    color, radii, grads, g2d, cap = run(1.0)
+    # the list structure twice: of the default run (tiles a splat provably misses are left out of the lists, csrc/gsr_rect_trim.h)
+    # and of a run that bins every tile of every rectangle like the reference (GSR_DEBUG_NO_TRIM): same image, bit for bit
+    color0, radii0, _, _, cap0 = run(1.0, _C.DEBUG_NO_TRIM)
+    assert torch.equal(color, color0) and torch.equal(radii, radii0), "the image must not notice what the binning leaves out"
+    listed = {}
+    for whole, (cap_k, radii_k) in ((False, (cap, radii)), (True, (cap0, radii0))):
+        listed[whole] = _list_structure(cap_k, radii_k, P, W, H, T, dev, whole)
+    assert listed[True] == cap["R"] and listed[False] <= listed[True]
+    line = f"[{name}] instances listed: {listed[False]} of {listed[True]} ({listed[False] / max(listed[True], 1):.3f}) -- the rest lie in tiles their splat provably misses"
+    print(line)
+    util.parity_log(line)
+    R = cap["R"]
+    il = _C.image_layout(W, H)
+    u32 = lambda buf, off, n: buf[off:off + 4 * n].view(torch.int32)
+    lens = (lambda r: r[:, 1] - r[:, 0])(u32(cap["img"], il.ranges, 2 * T).view(T, 2).to(torch.int64))
     final_T = cap["img"][il.final_T:il.final_T + 4 * W * H].view(torch.float32)
     assert bool(torch.isfinite(color).all()) and float(final_T.min()) >= 1e-4 * (1 - 1e-6) and float(final_T.max()) <= 1.0
     n_contrib = u32(cap["img"], il.n_contrib, W * H).to(torch.int64).view(H, W)

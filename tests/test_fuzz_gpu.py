@@ -131,14 +131,19 @@ def _binning_pair(scene, cam, D, dpix, label):
     o = util.oracle_forward(scene, cam, D)
     if dpix is None:
         dpix = util.fragile_free_dpix(o, cam, seed=5)
-    a = util.hip_forward_backward(scene, cam, D, dpix)
+    d = util.hip_forward_backward(scene, cam, D, dpix)   # the default: column pairs, tiles a splat provably misses left out (gsr_rect_trim.h)
+    a = util.hip_forward_backward(scene, cam, D, dpix, debug=_C.DEBUG_NO_TRIM)   # column pairs, every tile of every rectangle
     b = util.hip_forward_backward(scene, cam, D, dpix, debug=_C.DEBUG_TILE_SORT)
+    check_forward(d, o, cam)
     check_forward(a, o, cam)
     check_forward(b, o, cam)
+    for k in ("color", "radii", "final_T"):   # what is left out never contributed: the image cannot tell
+        assert np.array_equal(d[k], a[k]), (label, "trimmed", k)
     for k in ("color", "radii", "final_T", "n_contrib", "ranges"):
         assert np.array_equal(a[k], b[k]), (label, k)
     vis = a["tiles_touched"] > 0   # (slot_base is written for Gaussians with tiles only)
     assert np.array_equal(a["slot_base"][vis], b["slot_base"][vis]), (label, "slot_base")
+    assert np.array_equal(d["slot_base"][vis], b["slot_base"][vis]), (label, "slot_base, trimmed")
     if o["num_rendered"] > 0:
         for k in ("point_list", "keys"):
             assert np.array_equal(a[k], b[k]), (label, k)

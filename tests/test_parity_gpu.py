@@ -50,15 +50,18 @@ def check_forward(h, o, cam):
         assert np.array_equal(a, b), f"{k}: max abs diff {np.abs(a - b).max()}"
     cb = (o["clamped"][:, 0] | (o["clamped"][:, 1] << 1) | (o["clamped"][:, 2] << 2)).astype(np.uint8)
     np.testing.assert_array_equal(h["clamped_bits"][vis], cb[vis])
+    H, W = cam.image_height, cam.image_width
+    # the sorted instance list: the reference's (the oracle's), less the instances the binning was told to leave out -- tiles a splat
+    # provably misses (csrc/gsr_rect_trim.h; none with GSR_DEBUG_NO_TRIM and on the tile-sort path: then the lists are the oracle's own)
+    exp = util.trimmed_expectation(o, h["rshape"], W, H) if o["num_rendered"] > 0 else dict(ranges=o["ranges"], n_contrib=o["n_contrib"])
     if o["num_rendered"] > 0:
-        np.testing.assert_array_equal(h["point_list"], o["point_list"])
-        np.testing.assert_array_equal(h["keys"], o["keys"])
-    np.testing.assert_array_equal(h["ranges"], o["ranges"])
+        np.testing.assert_array_equal(h["point_list"], exp["point_list"])
+        np.testing.assert_array_equal(h["keys"], exp["keys"])
+    np.testing.assert_array_equal(h["ranges"], exp["ranges"])
     ok = o["fragile"] == 0
     frac = 1.0 - ok.mean()
     assert frac < 5e-3, f"too many fragile pixels: {frac}"
-    np.testing.assert_array_equal(h["n_contrib"][ok], o["n_contrib"][ok])
-    H, W = cam.image_height, cam.image_width
+    np.testing.assert_array_equal(h["n_contrib"][ok], exp["n_contrib"][ok])
     err = np.abs(h["color"].reshape(3, -1) - o["color"].reshape(3, -1))[:, ok]
     assert err.max() <= IMG_ATOL, f"image max abs err {err.max()} (mean {err.mean()})"
     errT = np.abs(h["final_T"] - o["final_T"])[ok]

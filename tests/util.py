@@ -140,6 +140,7 @@ def unpack_state(cap, P, W, H, tile_sort=False):
     o["depths"] = depth_bits.view(np.float32)
     o["slot_base"] = geom[gl.slot_base:gl.slot_base + 4 * P].view(np.uint32)
     o["rect"] = geom[gl.rect:gl.rect + 8 * P].view(np.uint32).reshape(P, 2)
+    o["rshape"] = geom[gl.rshape:gl.rshape + 8 * P].view(np.uint32).reshape(P, 2)   # {rectangle in one word, trim word}: csrc/gsr_rect_trim.h
     o["final_T"] = img[il.final_T:il.final_T + 4 * N].view(np.float32)
     o["n_contrib"] = img[il.n_contrib:il.n_contrib + 4 * N].view(np.uint32)
     o["ranges"] = img[il.ranges:il.ranges + 8 * T].view(np.uint32).reshape(T, 2)
@@ -150,10 +151,15 @@ def unpack_state(cap, P, W, H, tile_sort=False):
             # column-pair binning (csrc/tilebin.hip): no per-instance tile key is ever stored; the tile of sorted instance i is
             # the tile whose range holds i.  check_forward compares `ranges` and `point_list` with the oracle's directly; the
             # keys below then restate that (and fail loudly if the ranges do not partition [0, R))
+            # The list holds the instances the binning kept: all R of them with GSR_DEBUG_NO_TRIM, fewer otherwise (tiles a splat
+            # provably misses are left out, csrc/gsr_rect_trim.h) -- the ranges partition [0, listed) either way.
             lens = (o["ranges"][:, 1] - o["ranges"][:, 0]).astype(np.int64)
             ne = lens > 0
             starts = o["ranges"][ne, 0].astype(np.int64)
-            assert int(lens.sum()) == R and np.array_equal(starts, np.concatenate([[0], np.cumsum(lens[ne])[:-1]])), "ranges do not partition [0, R) in tile order"
+            listed = int(lens.sum())
+            assert listed <= R and np.array_equal(starts, np.concatenate([[0], np.cumsum(lens[ne])[:-1]])), "ranges do not partition [0, listed) in tile order"
+            assert listed == R or bool((o["rshape"][:, 1] != 0).any()), "instances are missing from the list although nothing was trimmed"
+            o["point_list"] = o["point_list"][:listed]
             o["tile_keys"] = np.repeat(np.arange(T, dtype=np.uint32), lens)
         else:
             kb = int(bl.tile_key_bytes)   # 2: uint16 tile ids (every id of the image < 65 536), 4: uint32
@@ -161,6 +167,54 @@ def unpack_state(cap, P, W, H, tile_sort=False):
         # the reference's 64-bit key of every sorted instance: tile id << 32 | depth bits
         o["keys"] = (o["tile_keys"].astype(np.uint64) << np.uint64(32)) | depth_bits[o["point_list"]].astype(np.uint64)
     return o
+
+
+def trim_kept(rshape, gauss, tile, gx):
+    """numpy restatement of the binning's reading of the trim words (csrc/gsr_rect_trim.h: gsr_rect_unpack, gsr_trim_of,
+    gsr_trim_columns): is instance (Gaussian gauss[i], tile tile[i]) -- a tile of that Gaussian's rectangle -- kept in the list?"""
+    P = rshape.shape[0]
+    packed, trim = rshape[:, 0].astype(np.int64), rshape[:, 1].astype(np.int64)
+    x0, y0, w, h = packed & 255, (packed >> 8) & 255, ((packed >> 16) & 255) + 1, (packed >> 24) + 1
+    active = (trim != 0) & (w <= 8) & (rshape[:, 0] != 0xFFFFFFFF)
+    first, last = np.full(P, 99, np.int64), np.full(P, -1, np.int64)   # first and last column that keeps a row
+    for c in range(8):
+        nib = (trim >> (4 * c)) & 15
+        keeps = (c < w) & ((nib & 3) + (nib >> 2) < h)
+        first = np.where(keeps & (first == 99), c, first)
+        last = np.where(keeps, c, last)
+    g = gauss.astype(np.int64)
+    t64 = tile.astype(np.int64)
+    c, r = t64 % gx - x0[g], t64 // gx - y0[g]
+    assert bool(((c >= 0) & (c < w[g]) & (r >= 0) & (r < h[g])).all()), "an instance lies outside its Gaussian's rectangle"
+    nib = np.where(c < 8, (trim[g] >> (4 * np.minimum(c, 7))) & 15, 0)
+    t, b = nib & 3, nib >> 2
+    whole = t + b >= h[g]   # (an empty column between kept ones: the producer makes none; the binning would take it whole)
+    rows_ok = whole | ((r >= t) & (r < h[g] - b))
+    return ~active[g] | ((c >= first[g]) & (c <= last[g]) & rows_ok)
+
+
+def trimmed_expectation(o, rshape, W, H):
+    """The oracle's sorted instance list, keys, tile ranges and n_contrib as they must look after the binning has left out the
+    instances the trim words name: same order, positions counted in the shorter lists (n_contrib = the position of the last
+    contributor in ITS tile's list -- a contributor is never left out)."""
+    gx, gy = (W + 15) // 16, (H + 15) // 16
+    T = gx * gy
+    rng = o["ranges"].astype(np.int64)
+    lens = rng[:, 1] - rng[:, 0]
+    tile_of = np.repeat(np.arange(T, dtype=np.int64), lens)   # (the oracle's ranges partition [0, R) in tile order)
+    kept = trim_kept(rshape, o["point_list"], tile_of, gx)
+    kcum = np.concatenate([[0], np.cumsum(kept)]).astype(np.int64)
+    new_len = kcum[rng[:, 1]] - kcum[rng[:, 0]]
+    new_start = kcum[rng[:, 0]]
+    ranges = np.where((new_len > 0)[:, None], np.stack([new_start, new_start + new_len], 1), 0).astype(np.uint32)
+    ys, xs = np.divmod(np.arange(W * H, dtype=np.int64), W)
+    tile_pix = (ys // 16) * gx + xs // 16
+    n = o["n_contrib"].astype(np.int64)
+    n_contrib = (kcum[rng[tile_pix, 0] + n] - kcum[rng[tile_pix, 0]]).astype(np.uint32)
+    # the last contributor itself must have been kept: position n - 1 of the tile's list
+    last = rng[tile_pix, 0] + n - 1
+    assert bool(kept[last[n > 0]].all()), "the binning left out an instance the oracle blends"
+    return dict(point_list=o["point_list"][kept], keys=o["keys"][kept], ranges=ranges, n_contrib=n_contrib, kept=kept, tile_of=tile_of)
 
 
 def fragile_free_dpix(o, cam, seed=1):

@@ -1,7 +1,8 @@
 """Randomised A/B of the two binning paths (column pairs, csrc/tilebin.hip, against instance emission + tile sort): many scenes,
 sizes from one tile to 4096 pixels a side, cameras outside and inside the cloud (rectangles of one tile up to the whole image), dense
 clumps (tile lists of tens of thousands).  Every scene: image, radii, the sorted instance list, the ranges, the gradient slots'
-numbering and n_contrib must be bit-identical.  No oracle involved, so a scene costs milliseconds.
+numbering and n_contrib must be bit-identical (both paths binning every tile of every rectangle, GSR_DEBUG_NO_TRIM on the column pairs), and the
+default run -- tiles a splat provably misses left out -- must give the same image.  No oracle involved, so a scene costs milliseconds.
 
     python tools/binning_stress.py [n_scenes=300] [seed0=0]        (GPU box, repo root)"""
 import os, sys, math
@@ -51,10 +52,16 @@ for k in range(n):
     cam = gsr_scene.make_camera(W, H, fovx=float(r.uniform(0.05, 2.4)), R=Rm, T=-Rm.T @ eye)
     dpix = torch.randn(3, H, W, generator=torch.Generator().manual_seed(k))
     try:
-        a = util.hip_forward_backward(scene, cam, D, dpix)
+        # a: column pairs binning every tile of every rectangle (GSR_DEBUG_NO_TRIM), b: instance emission + tile sort -- the reference's
+        # lists both; d: the default, column pairs without the tiles a splat provably misses (csrc/gsr_rect_trim.h): same image
+        a = util.hip_forward_backward(scene, cam, D, dpix, debug=_C.DEBUG_NO_TRIM)
         b = util.hip_forward_backward(scene, cam, D, dpix, debug=_C.DEBUG_TILE_SORT)
+        d = util.hip_forward_backward(scene, cam, D, None)
         keys = ["color", "radii", "final_T", "n_contrib", "ranges"] + (["point_list"] if a["num_rendered"] > 0 else [])
         diff = [x for x in keys if not np.array_equal(a[x], b[x])] + [x for x in a["grads"] if not np.array_equal(a["grads"][x], b["grads"][x])]
+        diff += ["default run: " + x for x in ("color", "radii", "final_T") if not np.array_equal(d[x], a[x])]
+        if d["num_rendered"] != a["num_rendered"] or (a["num_rendered"] > 0 and len(d["point_list"]) > len(a["point_list"])):
+            diff.append("default run: num_rendered / list length")
         if int(a["tiles_touched"].astype(np.int64).sum()) != int(a["num_rendered"]) or int(b["num_rendered"]) != int(a["num_rendered"]):
             diff.append("num_rendered != sum(tiles_touched): the count was read back before it was complete")
         vis = a["tiles_touched"] > 0   # (slot_base is written for Gaussians with tiles only)

@@ -9,7 +9,14 @@ Scene kinds: uniform cube; a dense clump (tile lists of tens of thousands); the 
 split and the backward's depth segments); Gaussians on a handful of distinct depths (the depth sort's copy levels); slabs of
 thousands of Gaussians on a few float steps; most Gaussians culled.
 
-    python tools/determinism_stress.py [n_scenes=60] [runs=6] [seed0=0]        (GPU box, repo root)"""
+The default binning leaves out tiles a splat provably misses (csrc/gsr_rect_trim.h); the tile-sort path bins every tile of the
+rectangle like the reference.  The image must not notice, and neither do the gradients -- except where a heavy tile's backward walk
+is cut into depth segments (checkpoints every 1024th LIST POSITION: the cuts fall on other instances when the list is shorter, and a
+segment's starting state is a difference of forward sums, 5e-7 away from the recurrence).  With base_mask = 8 (GSR_DEBUG_NO_SPLIT in
+every run) nothing is cut and every gradient must have the same bits on all three paths; without it the tile-sort comparison is
+bitwise on image and radii and to 1e-3 of the gradient's largest magnitude otherwise (5e-7 on the blend sums, times the covariance chain).
+
+    python tools/determinism_stress.py [n_scenes=60] [runs=6] [seed0=0] [base_mask=0]        (GPU box, repo root)"""
 import os
 import sys
 
@@ -27,6 +34,7 @@ dev = torch.device("cuda:0")
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 runs = int(sys.argv[2]) if len(sys.argv) > 2 else 6
 seed0 = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+base_mask = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 NAMES = ("means3D", "shs", "opacities", "scales", "rotations")
 
 
@@ -40,8 +48,11 @@ def render(scene_dev, st, dpix):
     return out
 
 
-def same(a, b):
-    return [k for k in a if not torch.equal(a[k].contiguous().view(torch.uint8), b[k].contiguous().view(torch.uint8))]
+def same(a, b, close=False):
+    d = [k for k in a if not torch.equal(a[k].contiguous().view(torch.uint8), b[k].contiguous().view(torch.uint8))]
+    if close:   # gradients: to 1e-3 of the tensor's largest magnitude (the image and the radii stay bitwise)
+        d = [k for k in d if not k.startswith("dL_") or float((a[k] - b[k]).abs().max()) > 1e-3 * max(float(a[k].abs().max()), 1e-30)]
+    return d
 
 
 bad = 0
@@ -83,14 +94,15 @@ for k in range(n):
     dpix = torch.randn(3, H, W, generator=torch.Generator().manual_seed(k)).to(dev)
     msg = []
     try:
-        first = render(scene_dev, util.hip_settings(scene, cam, D, dev), dpix)
+        first = render(scene_dev, util.hip_settings(scene, cam, D, dev, debug=base_mask), dpix)
         for it in range(1, runs):
-            d = same(first, render(scene_dev, util.hip_settings(scene, cam, D, dev), dpix))
+            d = same(first, render(scene_dev, util.hip_settings(scene, cam, D, dev, debug=base_mask), dpix))
             if d:
                 msg.append(f"run {it} differs from run 0 in {d}")
                 break
         for name, mask in (("radix depth passes", _C.DEBUG_RADIX_DEPTH), ("tile sort", _C.DEBUG_TILE_SORT)):
-            d = same(first, render(scene_dev, util.hip_settings(scene, cam, D, dev, debug=mask), dpix))
+            d = same(first, render(scene_dev, util.hip_settings(scene, cam, D, dev, debug=mask | base_mask), dpix),
+                     close=(mask == _C.DEBUG_TILE_SORT and not (base_mask & _C.DEBUG_NO_SPLIT)))
             if d:
                 msg.append(f"{name}: differs in {d}")
         torch.cuda.synchronize()
