@@ -85,12 +85,36 @@ def algorithmic_bytes(P, V, R, Rp, N, T, M):
     return fwd, bwd
 
 
-def binning_moved_bytes(P, V, R, T, pairs):
+def binning_moved_bytes(P, V, R, L, T, pairs):
     """Bytes the column-pair binning's three stage-2 kernels have to move by their own design (csrc/tilebin.hip): pass 1's scatter
-    reads the 16-byte depth-ordered records of all P Gaussians and writes one 8-byte column pair per (Gaussian, tile column) and the
-    visible Gaussians' slot bases; pass 2 reads the pairs twice (histogram, scatter) and writes 4 bytes per instance (point_list),
-    the validity byte per instance and 8 bytes per tile (ranges).  No per-instance key exists."""
-    return dict(col_scatter=16 * P + 8 * pairs + 4 * V, row_hist=8 * pairs, row_scatter=8 * pairs + 5 * R + 8 * T)
+    reads the 16-byte depth-ordered records of all P Gaussians and writes one 8-byte column pair per (Gaussian, tile column that keeps
+    a row) and the visible Gaussians' slot bases; pass 2 reads the pairs twice (histogram, scatter) and writes 4 bytes per LISTED
+    instance (point_list: L of the R instances -- tiles a splat provably misses are left out, csrc/gsr_rect_trim.h), one validity
+    byte per gradient slot (R) and 8 bytes per tile (ranges).  No per-instance key exists."""
+    return dict(col_scatter=16 * P + 8 * pairs + 4 * V, row_hist=8 * pairs, row_scatter=8 * pairs + 4 * L + R + 8 * T)
+
+
+def listed_counts(geom, img, P, W, H):
+    """(column pairs, instances) the column-pair binning actually lists for this view, from the geometry buffer's trim words and the
+    image buffer's tile ranges (torch restatement of gsr_trim_columns, csrc/gsr_rect_trim.h)."""
+    from diff_gaussian_rasterization import _C
+    gl, il = _C.geometry_layout(P), _C.image_layout(W, H)
+    T = ((W + 15) // 16) * ((H + 15) // 16)
+    rs = geom[gl.rshape:gl.rshape + 8 * P].view(torch.int32).view(P, 2).to(torch.int64) & 0xFFFFFFFF
+    packed, trim = rs[:, 0], rs[:, 1]
+    none = packed == 0xFFFFFFFF
+    w, h = ((packed >> 16) & 255) + 1, (packed >> 24) + 1
+    first, last = torch.full_like(w, 99), torch.full_like(w, -1)
+    for c in range(8):
+        nib = (trim >> (4 * c)) & 15
+        keeps = (c < w) & ((nib & 3) + (nib >> 2) < h)
+        first = torch.where(keeps & (first == 99), torch.full_like(w, c), first)
+        last = torch.where(keeps, torch.full_like(w, c), last)
+    active = (trim != 0) & (w <= 8)
+    wt = torch.where(active, torch.clamp(last - first + 1, min=0), w)
+    pairs = int(wt[~none].sum().item())
+    rng = img[il.ranges:il.ranges + 8 * T].view(torch.int32).view(T, 2).to(torch.int64)
+    return pairs, int((rng[:, 1] - rng[:, 0]).sum().item())
 
 
 def host_cores():
@@ -840,21 +864,19 @@ def run_rank(args, rank, world, dev, phase=None, grouped=None):
                                              "moves: pmc_traffic_bytes / traffic_frac")
     tb = [n for n in ("col_scatter", "row_hist", "row_scatter") if n in kern]
     if len(tb) == 3:
-        # column pairs of this view = sum over the visible Gaussians of their rectangles' widths (the geometry buffer's dense rectangles)
-        gl = _C.geometry_layout(P)
-        rect = cap["geom"][gl.rect:gl.rect + 8 * P].view(torch.int32).view(P, 2)[:, 1]
-        wdt, hgt = rect & 0xFFFF, (rect >> 16) & 0xFFFF
-        pairs = int(wdt[(wdt * hgt) > 0].sum().item())
-        moved = binning_moved_bytes(P, V, R, T, pairs)
+        # column pairs and instances of this view as the binning lists them (the geometry buffer's trim words, the tile ranges)
+        pairs, listed = listed_counts(cap["geom"], cap["img"], P, W, H)
+        moved = binning_moved_bytes(P, V, R, listed, T, pairs)
         for n in tb:
             kern[n].update(algorithmic_bytes=moved[n], GBps=round(moved[n] / (kern[n]["ms"] * 1e-3) / 1e9, 1),
                            hbm_frac=round(moved[n] / (kern[n]["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 3))
         ms = sum(kern[n]["ms"] for n in tb)
         mb = sum(moved.values())
-        kern["binning"] = dict(ms=round(ms, 4), launches=None, column_pairs=pairs, algorithmic_bytes=mb, GBps=round(mb / (ms * 1e-3) / 1e9, 1),
+        kern["binning"] = dict(ms=round(ms, 4), launches=None, column_pairs=pairs, instances_listed=listed, num_rendered=R, algorithmic_bytes=mb, GBps=round(mb / (ms * 1e-3) / 1e9, 1),
                                hbm_frac=round(mb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 3),
                                note="col_scatter + row_hist + row_scatter of the column-pair binning against the bytes THEY have to move "
-                                    "(16 P + 4 V + 24 B per column pair + 5 R + 8 T: no per-instance key exists); these kernels are bound by "
+                                    "(16 P + 4 V + 24 B per column pair + 4 B per listed instance + R + 8 T: no per-instance key exists; instances_listed of the "
+                                    "num_rendered instances are listed -- the others lie in tiles their splat provably misses, csrc/gsr_rect_trim.h); these kernels are bound by "
                                     "their LDS instruction stream and dependent round trips, not by bytes")
         if "depth_sort" in kern:
             cms = ms + kern["depth_sort"]["ms"]

@@ -1,10 +1,14 @@
 #!/bin/bash
-# The round's evidence in one go (GPU box, repo root): bash tools/final_profiles.sh <tag>   -> gpurun_out/<tag>_*
+# The round's evidence (GPU box, repo root): bash tools/final_profiles.sh <tag> [a|b|all]   -> gpurun_out/<tag>_*
+#   a: bench lines (C3, C2, C5), kernel stats + PMC of the step and of the extras;  b: tile clocks, skewed scenes, views in flight, parity report
+#   (two calls: together they exceed one gpurun call's 20 minutes)
 set -u
 TAG=${1:?tag}
+PART=${2:-all}
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 O=$ROOT/gpurun_out
 cd $ROOT
+if [ "$PART" != b ]; then
 for c in C3 C2 C5; do
   extra=""; [ "$c" != C3 ] && extra="--no-cpu-baseline --no-extras"
   timeout -k 10 400 python bench.py --config $c $extra 2>/dev/null | tail -1 > $O/${TAG}_bench_$(echo $c | tr A-Z a-z).json.log
@@ -13,6 +17,8 @@ done
 timeout -k 10 500 bash tools/profile_run.sh $TAG C3 > $O/${TAG}_profile_run.log 2>&1; tail -2 $O/${TAG}_profile_run.log
 rm -rf $O/$TAG/trace $O/$TAG/pmc_*/
 timeout -k 10 500 bash tools/profile_extras.sh ${TAG}x > $O/${TAG}_profile_extras.log 2>&1; tail -2 $O/${TAG}_profile_extras.log
+fi
+[ "$PART" = a ] && exit 0
 for s in uniform blob lowop; do
   k=""; [ "$s" = uniform ] && k="--forward-key --backward-key-length"
   timeout -k 10 300 python tools/tile_clock.py --config C3 --scene $s $k --out $O/${TAG}_tile_clock_c3_$s.txt > /dev/null 2>&1; tail -1 $O/${TAG}_tile_clock_c3_$s.txt | cut -c1-150
