@@ -66,6 +66,8 @@ __host__ __device__ __forceinline__ void gsr_trim_columns(uint32_t trim, uint32_
 __device__ __forceinline__ uint32_t gsr_rect_trim(float px, float py, float ca, float cb, float cc, float opacity, int x0, int y0, int w, int h)
 {
 	if (w > GSR_TRIM_MAX_COLUMNS || w <= 0 || h <= 0) return 0u;
+	// (v_sqrt_f32 / v_rcp_f32 / v_log_f32 as they are, 1 ulp: the margins below are a thousand times that; the IEEE expansions of
+	// sqrtf and of the division cost the geometry kernel, which the whole binning chain waits for, 7 us at 1 M Gaussians)
 	const float det = ca * cc - cb * cb;
 	// q = ca dx^2 + 2 cb dx dy + cc dy^2 <= tau is necessary for alpha >= 1 / 255; the margin (0.1 % + 0.01) is thousands of times the
 	// error of the kernels' fp32 `power` and exp at these magnitudes (tau <= 11.1)
@@ -74,10 +76,11 @@ __device__ __forceinline__ uint32_t gsr_rect_trim(float px, float py, float ca, 
 	uint32_t trim = 0u;
 	uint32_t first = (uint32_t)w, last = 0u;
 	if (tau > 0.0f) {
-		const float ex = sqrtf(tau * cc / det) * 1.0001f + 0.01f;      // half width of the ellipse
-		const float eyy = sqrtf(tau * ca / det) * 1.0001f + 0.01f;     // half height
-		const float xs = -cb * sqrtf(tau / (det * ca));                // dx of the ellipse's bottom point (largest dy); its top point: -xs
-		const float inv_cc = 1.0f / cc;
+		const float inv_det = __builtin_amdgcn_rcpf(det);
+		const float ex = __builtin_amdgcn_sqrtf(tau * cc * inv_det) * 1.0001f + 0.01f;      // half width of the ellipse
+		const float eyy = __builtin_amdgcn_sqrtf(tau * ca * inv_det) * 1.0001f + 0.01f;     // half height
+		const float xs = -cb * __builtin_amdgcn_sqrtf(tau * inv_det * __builtin_amdgcn_rcpf(ca));                // dx of the ellipse's bottom point (largest dy); its top point: -xs
+		const float inv_cc = __builtin_amdgcn_rcpf(cc);
 #pragma unroll
 		for (int c = 0; c < GSR_TRIM_MAX_COLUMNS; c++) {
 			if (c >= w) break;
@@ -87,7 +90,7 @@ __device__ __forceinline__ uint32_t gsr_rect_trim(float px, float py, float ca, 
 			if (lo <= ex && hi >= -ex) {
 				lo = fmaxf(lo, -ex); hi = fminf(hi, ex);
 				// largest dy over the strip: the ellipse's bottom point if its dx lies inside, else at the nearer end (the boundary is concave)
-				const float rlo = sqrtf(fmaxf(0.0f, tau * cc - det * lo * lo)), rhi = sqrtf(fmaxf(0.0f, tau * cc - det * hi * hi));
+				const float rlo = __builtin_amdgcn_sqrtf(fmaxf(0.0f, tau * cc - det * lo * lo)), rhi = __builtin_amdgcn_sqrtf(fmaxf(0.0f, tau * cc - det * hi * hi));
 				float ymax = fmaxf((-cb * lo + rlo) * inv_cc, (-cb * hi + rhi) * inv_cc);
 				float ymin = fminf((-cb * lo - rlo) * inv_cc, (-cb * hi - rhi) * inv_cc);
 				if (lo <= xs && xs <= hi) ymax = eyy;
