@@ -272,23 +272,23 @@ static uint32_t* g_debug_forward_key = nullptr;
 extern "C" int gsr_debug_forward_key(uint32_t* key) { g_debug_forward_key = key; return 0; }
 #endif
 
-// Forward only (split_bin_max >= 0): HEAVY tiles are handed out as four entries, one per 16x4-pixel band (entry = tile |
+// Forward only (split_min > 0): HEAVY tiles are handed out as four entries, one per 16x4-pixel band (entry = tile |
 // (band + 1) << 28; the forward kernel then blends that band alone, one pixel per lane).  A tile's pixels are independent, so
 // nothing changes in any result; what changes is the longest job of the launch: on a scene whose heaviest tiles carry 20-30x
 // the mean list and are walked to the end (low opacities), the one wave of the heaviest tile WAS the launch (342 of 342 us,
-// profiles/r3_tile_clock_c3_lowop.txt).  Heavy = range length >= 16 * (GSR_ORDER_BINS - 1 - split_bin_max), the heaviest
+// profiles/r3_tile_clock_c3_lowop.txt).  Heavy = range length >= max(split_min, 2 x the mean listed range), the heaviest
 // first, at most max_split tiles; the entries [ntiles + 3 nsplit, ntiles + 3 max_split) are marked empty.
 // (ranges and ranges_fix are the same array when the forward normalises empty tiles: neither may be __restrict__; what is written
 // there -- (0, 0) over (p, p) -- leaves every tile's work at 0, so the later reads through `ranges` see the same work either way)
 __global__ void __launch_bounds__(1024) gsr_tile_order_kernel(const uint2* ranges, const uint32_t* __restrict__ tile_max_contrib,
-                                                              uint32_t ntiles, uint32_t* __restrict__ order, int split_bin_max, uint32_t max_split,
+                                                              uint32_t ntiles, uint32_t* __restrict__ order, uint32_t split_min, uint32_t max_split,
                                                               uint32_t* tile_max_contrib_out, uint32_t seg_budget, int allow_cut,
                                                               uint2* ranges_fix)
 {
 	__shared__ uint32_t bin[GSR_ORDER_BINS];
 	__shared__ uint32_t wsum[1024 / 64];
-	__shared__ uint32_t s_nsplit, s_seg_items[4], s_seg_cursor, s_incl[GSR_ORDER_BINS];
-	if (threadIdx.x == 0) { s_nsplit = 0u; s_seg_cursor = 0u; }
+	__shared__ uint32_t s_nsplit, s_seg_items[4], s_seg_cursor, s_incl[GSR_ORDER_BINS], s_total;
+	if (threadIdx.x == 0) { s_nsplit = 0u; s_seg_cursor = 0u; s_total = 0u; }
 	if (threadIdx.x < 4) s_seg_items[threadIdx.x] = 0u;
 	bin[threadIdx.x] = 0;
 	// The kernel is one workgroup of dependent round trips: every pass reads GSR_ORDER_PER_THREAD tiles per thread with all
@@ -329,21 +329,36 @@ __global__ void __launch_bounds__(1024) gsr_tile_order_kernel(const uint2* range
 		for (int f = 0; f < 4; f++)
 			if (my_items[f]) atomicAdd(&s_seg_items[f], my_items[f]);
 	}
+	uint32_t my_work = 0u;   // (forward: the listed instances of this thread's tiles -- the mean list decides what is heavy)
 #pragma unroll
 	for (int j = 0; j < GSR_ORDER_PER_THREAD; j++)
-		if (b0[j] != 0xffffffffu) atomicAdd(&bin[b0[j]], 1u);
+		if (b0[j] != 0xffffffffu) { atomicAdd(&bin[b0[j]], 1u); my_work += w0[j]; }
 	for (uint32_t base = 1024 * GSR_ORDER_PER_THREAD; base < ntiles; base += 1024 * GSR_ORDER_PER_THREAD) {
 		uint32_t b[GSR_ORDER_PER_THREAD];
 #pragma unroll
 		for (int j = 0; j < GSR_ORDER_PER_THREAD; j++) {
 			const uint32_t t = base + j * 1024 + threadIdx.x;
-			b[j] = t < ntiles ? gsr_tile_work_bin(gsr_tile_work(ranges, tile_max_contrib, t)) : 0xffffffffu;
+			const uint32_t w = t < ntiles ? gsr_tile_work(ranges, tile_max_contrib, t) : 0u;
+			b[j] = t < ntiles ? gsr_tile_work_bin(w) : 0xffffffffu;
+			my_work += w;
 		}
 #pragma unroll
 		for (int j = 0; j < GSR_ORDER_PER_THREAD; j++)
 			if (b[j] != 0xffffffffu) atomicAdd(&bin[b[j]], 1u);
 	}
+	if (split_min) {   // one LDS atomic per wave, not per thread (1 024 adders on one address are microseconds in a one-workgroup kernel)
+#pragma unroll
+		for (int off = 32; off > 0; off >>= 1) my_work += (uint32_t)__shfl_xor((int)my_work, off, 64);
+		if ((threadIdx.x & 63) == 0 && my_work) atomicAdd(&s_total, my_work);
+	}
 	__syncthreads();
+	// heavy (forward only, split_min > 0): a list of at least split_min instances that is also at least twice the MEAN list -- the mean
+	// of what is listed (the binning leaves out the tiles a splat provably misses: only the device knows how many are left)
+	int split_bin_max = -1;
+	if (split_min) {
+		const uint32_t heavy = max(split_min, 2u * (s_total / max(ntiles, 1u)));
+		split_bin_max = GSR_ORDER_BINS - 1 - (int)min((heavy + 15u) / 16u, (uint32_t)GSR_ORDER_BINS - 1u);
+	}
 	const uint32_t c = bin[threadIdx.x];
 	uint32_t total;
 	const uint32_t incl = gsr_block_incl_scan<1024>(c, &total, wsum);
@@ -413,22 +428,18 @@ void gsr_launch_tile_order(GsrImage img, int ntiles, bool backward, int64_t num_
 	if (backward && g_debug_backward_key) { key = g_debug_backward_key; ranges = nullptr; }
 	if (!backward && g_debug_forward_key) { key = g_debug_forward_key; ranges = nullptr; split = false; }
 #endif
-	// heavy (forward only): a list of at least 1024 instances that is also at least twice the mean list (how deep a list is
-	// walked is not known before the forward has run; on the low-opacity blob scene the tiles that set the span were walked
-	// 2 400 - 3 300 deep whatever their length, 2 - 25 x the mean)
-	int split_bin_max = -1;
+	// heavy (forward only): a list of at least GSR_SPLIT_MIN_LIST instances that is also at least twice the mean list, which the kernel
+	// takes from the ranges (how deep a list is walked is not known before the forward has run; on the low-opacity blob scene the
+	// tiles that set the span were walked deep whatever their length, 2 - 25 x the mean)
+	(void)num_rendered;
 	const uint32_t max_split = backward ? 0u : gsr_tile_order_max_split(ntiles);   // the forward's list always has this room
-	if (!backward && split && max_split) {
-		const int64_t mean = num_rendered / (ntiles > 0 ? ntiles : 1);
-		const int64_t heavy = mean * 2 > 1024 ? mean * 2 : 1024;
-		split_bin_max = GSR_ORDER_BINS - 1 - (int)((heavy + 15) / 16 < GSR_ORDER_BINS - 1 ? (heavy + 15) / 16 : GSR_ORDER_BINS - 1);
-	}
+	const uint32_t split_min = (!backward && split && max_split) ? (uint32_t)GSR_SPLIT_MIN_LIST : 0u;
 	const uint32_t seg_budget = backward ? gsr_tile_order_max_segments(ntiles) : 0u;   // the backward's list always has this room
 	int allow_cut = split ? 1 : 0;
 #ifdef GSR_TILE_CLOCK
 	if (!ranges) allow_cut = 0;
 #endif
-	hipLaunchKernelGGL(gsr_tile_order_kernel, dim3(1), dim3(1024), 0, s, ranges, key, (uint32_t)ntiles, img.tile_order, split_bin_max, max_split,
+	hipLaunchKernelGGL(gsr_tile_order_kernel, dim3(1), dim3(1024), 0, s, ranges, key, (uint32_t)ntiles, img.tile_order, split_min, max_split,
 	                   img.tile_max_contrib, seg_budget, allow_cut, (normalise_empty && !backward) ? img.ranges : (uint2*)nullptr);
 }
 

@@ -51,7 +51,12 @@ struct GsrGeometry {
 // of a list (render_backward.hip).  One 4-KB record (256 pixels x float4) per checkpoint, indexed by the checkpoint's position in the
 // global sorted instance list: record (range.x + p) / GSR_CKPT_STRIDE for local position p -- tiles own disjoint ranges and only
 // tiles of at least two strides store any, so no two checkpoints share a record.
-#define GSR_CKPT_STRIDE 1024
+#ifndef GSR_CKPT_STRIDE
+#define GSR_CKPT_STRIDE 512    // (1024 until the lists were trimmed: gsr_rect_trim.h -- a list position now holds a contributor 1.6 x as often)
+#endif
+#ifndef GSR_SPLIT_MIN_LIST
+#define GSR_SPLIT_MIN_LIST 640 // forward: shortest list that is handed out as four band waves (1024 until the lists were trimmed)
+#endif
 #define GSR_CKPT_MAX_SEGMENTS 15   // segments a heavy tile's walk is cut into at most (4 bits of the dispatch entry, 0 = whole tile)
 static inline size_t gsr_checkpoint_records(int64_t R) { return (size_t)(R / GSR_CKPT_STRIDE) + 2; }
 

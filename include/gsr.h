@@ -53,7 +53,7 @@ typedef enum {
 #define GSR_DEBUG_NO_TRIM 64 /* gsr_forward_preprocess*: every tile of a Gaussian's rectangle is binned, like the reference does; default: tiles that
                                 the splat's ellipse at alpha = 1 / 255 provably misses are left out of point_list (csrc/gsr_rect_trim.h: same
                                 image, radii, gradients and num_rendered, bit for bit; shorter tile lists) */
-#define GSR_DEBUG_NO_SPLIT 8 /* gsr_forward_render: heavy tiles (instance lists >= 1024 and >= 2x the mean) are blended by one wave like
+#define GSR_DEBUG_NO_SPLIT 8 /* gsr_forward_render: heavy tiles (instance lists >= 640 and >= 2x the mean) are blended by one wave like
                                 every other tile, not by four waves of one 16x4-pixel band each (same results either way) */
 
 /* Message of the last failing call on this thread ("" if none). */
@@ -116,12 +116,14 @@ typedef struct {
 } gsr_image_layout;
 
 typedef struct {
-	size_t point_list;     /* [R] u32 Gaussian ids sorted by (tile, depth, id) -- the reference's point_list */
+	size_t point_list;     /* [R] u32 Gaussian ids sorted by (tile, depth, id) -- the reference's point_list; with the column-pair binning its
+	                          first L <= R entries: the instances in tiles their splat provably cannot reach at alpha = 1 / 255 are left out
+	                          (gsr_geometry_layout.rshape's trim words; L = sum of the tile ranges' lengths; L = R with GSR_DEBUG_NO_TRIM) */
 	size_t point_list_alt; /* [R] u32 sort ping-pong */
 	size_t tile_keys;      /* [R] tile id of each sorted instance (the high word of the reference's key), tile_key_bytes each */
 	size_t tile_keys_alt;  /* [R] sort ping-pong; after the forward its first R bytes are the backward's slot validity flags */
 	size_t sort_table;     /* radix histogram table of the tile sort */
-	size_t checkpoints;    /* [R / 1024 + 2][256] float4: per-pixel (T, C) of heavy tiles every 1024 instances of their walk */
+	size_t checkpoints;    /* [R / 512 + 2][256] float4: per-pixel (T, C) of heavy tiles every 512 list positions of their walk */
 	size_t total;
 	size_t tile_key_bytes; /* 2 (uint16_t: every tile id of the image is below 65 536) or 4 (uint32_t); both arrays are sized for 4 */
 	size_t column_pairs;   /* 1: images of at most 256 x 256 tiles are binned by column pairs (no per-instance tile keys exist: the tile

@@ -201,7 +201,7 @@ def _heavy_scene():
 def test_heavy_tiles_split_in_bands_and_in_depth():
     """Heavy tiles are split twice.  FORWARD: four entries, one wave per 16x4-pixel band (binning.hip gsr_tile_order_kernel);
     a tile's pixels are independent, so image, radii and all state must be bit-identical to the unsplit run
-    (GSR_DEBUG_NO_SPLIT).  BACKWARD: one wave per depth segment of 1024 instances, each starting from the per-pixel (T, C)
+    (GSR_DEBUG_NO_SPLIT).  BACKWARD: one wave per depth segment of 512 list positions, each starting from the per-pixel (T, C)
     checkpoint the forward left (render_backward.hip); accum_rec then comes from a difference of forward sums instead of the
     reference's recurrence, so the gradients agree with the unsplit run to rounding (<= 2e-6 of the largest element on the blend sums), not bit
     for bit -- and both must sit inside the oracle's bars (check_grads).  Both splits must actually have happened."""
@@ -247,7 +247,8 @@ def test_heavy_tiles_split_in_bands_and_in_depth():
     assert nsplit >= 1 and int((band > 0).sum()) == 4 * nsplit, "the blob's tiles must have been split into bands"
     assert valid.numel() == T + 3 * nsplit
     tiles = valid & 0x0FFFFFFF
-    assert int(lens[tiles[band > 0]].min()) >= max(1024, 2 * (R // T)) - 16, "only heavy tiles are split"
+    # heavy: at least 640 listed instances and at least twice the mean LISTED range (binning.hip; the order kernel bins lengths by 16)
+    assert int(lens[tiles[band > 0]].min()) >= max(640, 2 * (int(lens.sum()) // T)) - 16, "only heavy tiles are split"
     tmc = img[il.tile_max_contrib:il.tile_max_contrib + 4 * T].view(torch.int32).to(torch.int64)
     walked = torch.minimum(lens, tmc)
     _C.rasterize_gaussians_backward(st.bg, t["means3D"], radii, e, t["scales"], t["rotations"], 1.0, e, st.viewmatrix, st.projmatrix, st.tanfovx,
@@ -259,7 +260,7 @@ def test_heavy_tiles_split_in_bands_and_in_depth():
     cut = torch.unique(tiles[seg > 0])
     coarse = int(img[il.tile_order + 4 * (T + min(4096, T // 2)):il.tile_order + 4 * (T + min(4096, T // 2)) + 4].view(torch.int32)[0])
     assert coarse in (1, 2, 4, 8) and cut.numel() >= 1, "tiles walked deep must have been cut in depth"
-    assert torch.equal(torch.sort(cut).values, torch.nonzero(walked >= (coarse + 1) * 1024).flatten())
+    assert torch.equal(torch.sort(cut).values, torch.nonzero(walked >= (coarse + 1) * 512).flatten())   # (GSR_CKPT_STRIDE = 512 list positions)
     assert valid.numel() == T + int((seg > 0).sum()) - cut.numel()
     print(f"coarseness {coarse}; {nsplit} of {T} tiles split in bands (longest list {int(lens.max())}, mean {R // T}); {cut.numel()} cut in depth into "
           f"{int((seg > 0).sum())} segments (deepest walk {int(walked.max())})")
