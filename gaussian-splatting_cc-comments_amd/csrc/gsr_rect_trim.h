@@ -87,7 +87,7 @@ __device__ __forceinline__ uint32_t gsr_rect_trim(float px, float py, float ca, 
 			// the strip of pixel centres of tile column x0 + c, relative to the centre, widened by the margin
 			float lo = (float)((x0 + c) * GSR_TILE_X) - px - 0.01f, hi = (float)((x0 + c) * GSR_TILE_X + (GSR_TILE_X - 1)) - px + 0.01f;
 			uint32_t t = GSR_TRIM_MAX_ROWS, b = GSR_TRIM_MAX_ROWS;   // the ellipse misses the strip: as much off as the word can say
-			if (lo <= ex && hi >= -ex) {
+			if (!(lo > ex) && !(hi < -ex)) {   // (written so that a NaN anywhere keeps the column whole: every comparison below is false then)
 				lo = fmaxf(lo, -ex); hi = fminf(hi, ex);
 				// largest dy over the strip: the ellipse's bottom point if its dx lies inside, else at the nearer end (the boundary is concave)
 				const float rlo = __builtin_amdgcn_sqrtf(fmaxf(0.0f, tau * cc - det * lo * lo)), rhi = __builtin_amdgcn_sqrtf(fmaxf(0.0f, tau * cc - det * hi * hi));
@@ -99,6 +99,7 @@ __device__ __forceinline__ uint32_t gsr_rect_trim(float px, float py, float ca, 
 				ymin = ymin * 1.0001f - 0.01f;
 				// tile rows that hold a pixel centre in [py + ymin, py + ymax] -- or fewer: rows of the bounds themselves
 				const float r0 = floorf((py + ymin) * (1.0f / GSR_TILE_Y)), r1 = floorf((py + ymax) * (1.0f / GSR_TILE_Y));
+				// (fmaxf / fminf return their other operand for a NaN: 0 rows then)
 				const float tf = fminf(fmaxf(r0 - (float)y0, 0.0f), (float)GSR_TRIM_MAX_ROWS);
 				const float bf = fminf(fmaxf((float)(y0 + h - 1) - r1, 0.0f), (float)GSR_TRIM_MAX_ROWS);
 				t = (uint32_t)tf; b = (uint32_t)bf;
