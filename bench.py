@@ -104,14 +104,20 @@ def listed_counts(geom, img, P, W, H):
     packed, trim = rs[:, 0], rs[:, 1]
     none = packed == 0xFFFFFFFF
     w, h = ((packed >> 16) & 255) + 1, (packed >> 24) + 1
+    cs, rsh = torch.zeros_like(w), torch.zeros_like(w)   # log2 of the columns per nibble / rows per unit
+    for _ in range(6):
+        cs = torch.where(((w + (1 << cs) - 1) >> cs) > 8, cs + 1, cs)
+        rsh = torch.where(((h + (1 << rsh) - 1) >> rsh) > 16, rsh + 1, rsh)
+    groups = (w + (1 << cs) - 1) >> cs
     first, last = torch.full_like(w, 99), torch.full_like(w, -1)
     for c in range(8):
         nib = (trim >> (4 * c)) & 15
-        keeps = (c < w) & ((nib & 3) + (nib >> 2) < h)
+        keeps = (c < groups) & ((((nib & 3) + (nib >> 2)) << rsh) < h)
         first = torch.where(keeps & (first == 99), torch.full_like(w, c), first)
         last = torch.where(keeps, torch.full_like(w, c), last)
-    active = (trim != 0) & (w <= 8)
-    wt = torch.where(active, torch.clamp(last - first + 1, min=0), w)
+    active = trim != 0
+    kept_cols = torch.clamp(torch.minimum((last + 1) << cs, w) - (first << cs), min=0)
+    wt = torch.where(active, torch.where(last >= 0, kept_cols, torch.zeros_like(w)), w)
     pairs = int(wt[~none].sum().item())
     rng = img[il.ranges:il.ranges + 8 * T].view(torch.int32).view(T, 2).to(torch.int64)
     return pairs, int((rng[:, 1] - rng[:, 0]).sum().item())

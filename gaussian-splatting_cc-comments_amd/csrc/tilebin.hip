@@ -131,8 +131,8 @@ struct TbOwnRow {
 	__device__ uint32_t b() const { return v.y; }
 	__device__ uint32_t c() const { return 0u; }
 };
-// pass 1: a = the column's rows before trimming (y0 | (h - 1) << 8) with the number of the rectangle's first kept column in bits 16..18,
-// b = Gaussian id, c = the rectangle's trim word (gsr_rect_trim.h)
+// pass 1: a = the column's rows before trimming (y0 | (h - 1) << 8), the number of the rectangle's first kept column in bits 16..23 and
+// log2 of the columns per nibble / rows per unit of the trim word in bits 24..26 / 27..29; b = Gaussian id, c = the rectangle's trim word (gsr_rect_trim.h)
 struct TbOwnCol {
 	uint4 v;
 	static __device__ TbOwnCol make(uint32_t start, uint32_t d0, uint32_t a, uint32_t b, uint32_t c = 0u) { TbOwnCol o; o.v = make_uint4(start | (d0 << 16), a, b, c); return o; }
@@ -353,7 +353,7 @@ __global__ void __launch_bounds__(TB_THREADS) gsr_tb_col_scatter_kernel(const ui
 			len[q] = wt;              // one element per column that keeps a row
 			d0[q] = x0 + lead;
 			trim[q] = sg[q].y;
-			key[q] = y0 | ((h - 1u) << 8) | (lead << 16);
+			key[q] = y0 | ((h - 1u) << 8) | (lead << 16) | (gsr_trim_col_shift(w) << 24) | (gsr_trim_row_shift(h) << 27);
 			incl_t[q] = tb_wave_incl_scan(tiles[q]);
 			if (lane == 63) gsum[wave * TB_GROUPS + q] = incl_t[q];
 		}
@@ -377,8 +377,9 @@ __global__ void __launch_bounds__(TB_THREADS) gsr_tb_col_scatter_kernel(const ui
 			                [&](uint32_t pos, const TbOwnCol& own, uint32_t e) {
 				                // the rows this column keeps: its rectangle's, less what the trim word takes off its top and bottom
 				                uint32_t t, b;
-				                gsr_trim_of(own.c(), (own.a() >> 16) + e, t, b);
-				                if (t + b > ((own.a() >> 8) & 0xffu)) t = b = 0u;   // (an empty column between kept ones: the producer leaves none; whole if it did)
+				                const uint32_t h1 = (own.a() >> 8) & 0xffu;   // h - 1
+				                gsr_trim_of(own.c(), ((own.a() >> 16) & 0xffu) + e, (own.a() >> 24) & 7u, own.a() >> 27, t, b);
+				                if (t + b > h1) t = b = 0u;   // (an empty column between kept ones: the producer leaves none; whole if it did)
 				                const uint32_t rows = (own.a() & 0xffffu) + t - ((t + b) << 8);   // (y0 + t) | (h - t - b - 1) << 8
 				                if (pos < capacity) cpair[pos] = make_uint2(rows, own.b());   // always true for consistent tables; a corrupted table must not turn into a wild store
 			                });

@@ -99,7 +99,8 @@ typedef struct {
 	size_t col_table;      /* column-pair binning, pass 1 (by tile column): chunk sums, per-workgroup digit rows, 256 digit totals, the
 	                          Gaussians' {rectangle, id} records in depth order and (bucket depth sort) in bucket order, 16 B each */
 	size_t rshape;         /* [P] uint2 {rectangle in one word: x | y << 8 | (w - 1) << 16 | (h - 1) << 24, 0xFFFFFFFF = no tiles; trim word:
-	                          a nibble per tile column of the rectangle, rows left out at its top (2 bits) and bottom (2 bits)}: what the
+	                          a nibble per tile column of the rectangle (per group of 2 .. 32 columns when it is wider than 8), rows left out at its top
+	                          (2 bits) and bottom (2 bits; in units of 2 .. 16 rows when it is taller than 16)}: what the
 	                          column-pair binning reads (csrc/gsr_rect_trim.h) */
 	size_t total;
 } gsr_geometry_layout;

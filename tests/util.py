@@ -170,27 +170,34 @@ def unpack_state(cap, P, W, H, tile_sort=False):
 
 
 def trim_kept(rshape, gauss, tile, gx):
-    """numpy restatement of the binning's reading of the trim words (csrc/gsr_rect_trim.h: gsr_rect_unpack, gsr_trim_of,
-    gsr_trim_columns): is instance (Gaussian gauss[i], tile tile[i]) -- a tile of that Gaussian's rectangle -- kept in the list?"""
+    """numpy restatement of the binning's reading of the trim words (csrc/gsr_rect_trim.h: gsr_rect_unpack, gsr_trim_col_shift,
+    gsr_trim_row_shift, gsr_trim_of, gsr_trim_columns): is instance (Gaussian gauss[i], tile tile[i]) -- a tile of that Gaussian's
+    rectangle -- kept in the list?"""
     P = rshape.shape[0]
     packed, trim = rshape[:, 0].astype(np.int64), rshape[:, 1].astype(np.int64)
     x0, y0, w, h = packed & 255, (packed >> 8) & 255, ((packed >> 16) & 255) + 1, (packed >> 24) + 1
-    active = (trim != 0) & (w <= 8) & (rshape[:, 0] != 0xFFFFFFFF)
-    first, last = np.full(P, 99, np.int64), np.full(P, -1, np.int64)   # first and last column that keeps a row
-    for c in range(8):
-        nib = (trim >> (4 * c)) & 15
-        keeps = (c < w) & ((nib & 3) + (nib >> 2) < h)
-        first = np.where(keeps & (first == 99), c, first)
-        last = np.where(keeps, c, last)
+    cs, rs = np.zeros(P, np.int64), np.zeros(P, np.int64)   # log2 of the columns per nibble / rows per unit
+    for _ in range(6):
+        cs = np.where(((w + (1 << cs) - 1) >> cs) > 8, cs + 1, cs)
+        rs = np.where(((h + (1 << rs) - 1) >> rs) > 16, rs + 1, rs)
+    groups = (w + (1 << cs) - 1) >> cs
+    active = (trim != 0) & (rshape[:, 0] != 0xFFFFFFFF)
+    first, last = np.full(P, 99, np.int64), np.full(P, -1, np.int64)   # first and last column GROUP that keeps a row
+    for g_ in range(8):
+        nib = (trim >> (4 * g_)) & 15
+        keeps = (g_ < groups) & ((((nib & 3) + (nib >> 2)) << rs) < h)
+        first = np.where(keeps & (first == 99), g_, first)
+        last = np.where(keeps, g_, last)
     g = gauss.astype(np.int64)
     t64 = tile.astype(np.int64)
     c, r = t64 % gx - x0[g], t64 // gx - y0[g]
     assert bool(((c >= 0) & (c < w[g]) & (r >= 0) & (r < h[g])).all()), "an instance lies outside its Gaussian's rectangle"
-    nib = np.where(c < 8, (trim[g] >> (4 * np.minimum(c, 7))) & 15, 0)
-    t, b = nib & 3, nib >> 2
-    whole = t + b >= h[g]   # (an empty column between kept ones: the producer makes none; the binning would take it whole)
+    grp = c >> cs[g]
+    nib = (trim[g] >> (4 * (grp & 7))) & 15
+    t, b = (nib & 3) << rs[g], (nib >> 2) << rs[g]
+    whole = t + b >= h[g]   # (an empty group between kept ones: the producer makes none; the binning would take it whole)
     rows_ok = whole | ((r >= t) & (r < h[g] - b))
-    return ~active[g] | ((c >= first[g]) & (c <= last[g]) & rows_ok)
+    return ~active[g] | ((grp >= first[g]) & (grp <= last[g]) & rows_ok)
 
 
 def trimmed_expectation(o, rshape, W, H):
