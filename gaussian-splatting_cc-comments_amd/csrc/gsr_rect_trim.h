@@ -38,8 +38,9 @@ __host__ __device__ __forceinline__ void gsr_rect_unpack(uint32_t r, uint32_t& x
 
 // log2 of the columns that share a nibble (w <= 8: 0) and of the rows per unit (h <= 16: 0): the smallest powers of two with
 // at most 8 groups / at most 16 units
-__host__ __device__ __forceinline__ uint32_t gsr_trim_col_shift(uint32_t w) { uint32_t s = 0u; while (((w + (1u << s) - 1u) >> s) > (uint32_t)GSR_TRIM_GROUPS) s++; return s; }
-__host__ __device__ __forceinline__ uint32_t gsr_trim_row_shift(uint32_t h) { uint32_t s = 0u; while (((h + (1u << s) - 1u) >> s) > 16u) s++; return s; }
+// (w <= 8 * 2^s  <=>  s >= log2(w) - 3: no loop -- pass 1's scatter decodes a word per Gaussian, and a data-dependent loop there cost it 10 us)
+__host__ __device__ __forceinline__ uint32_t gsr_trim_col_shift(uint32_t w) { return w <= 8u ? 0u : 29u - (uint32_t)__builtin_clz(w - 1u); }
+__host__ __device__ __forceinline__ uint32_t gsr_trim_row_shift(uint32_t h) { return h <= 16u ? 0u : 28u - (uint32_t)__builtin_clz(h - 1u); }
 
 // rows taken off column c (< w) of a w x h rectangle: top (small y), bottom.  col_shift / row_shift: gsr_trim_col_shift(w), gsr_trim_row_shift(h)
 __host__ __device__ __forceinline__ void gsr_trim_of(uint32_t trim, uint32_t c, uint32_t col_shift, uint32_t row_shift, uint32_t& top, uint32_t& bottom)
