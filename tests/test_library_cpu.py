@@ -182,3 +182,40 @@ def test_barrier_audit_sees_a_missing_wait(tmp_path):
     assert subprocess.run([sys.executable, tool, str(good)]).returncode == 0
     r = subprocess.run([sys.executable, tool, str(bad)], capture_output=True, text=True)
     assert r.returncode == 1 and "bad.s:3" in r.stdout
+
+
+def test_trim_word_decoder_host_and_numpy_restatement_agree():
+    """csrc/gsr_rect_trim.h's decoder (what pass 1 of the binning does with a rectangle's trim word) compiled for the host
+    (tests/cpp/trim_decode.cpp) against tests/util.trim_kept -- the numpy restatement from which the GPU parity tests derive the lists
+    they expect -- on random rectangles of every size class (one nibble per column / per group of 2 .. 32 columns, rows in units of
+    1 .. 16) and random words, including words no producer writes (empty groups between kept ones)."""
+    import shutil
+    import subprocess
+    import sys
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import util
+    if not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("no hipcc")
+    exe = os.path.join(ROOT, "tests", "cpp", "trim_decode")
+    subprocess.run(["/opt/rocm/bin/hipcc", "--cuda-host-only", "-O1", "-std=c++17", "-o", exe, os.path.join(ROOT, "tests", "cpp", "trim_decode.cpp")],
+                   check=True, capture_output=True)
+    r = np.random.default_rng(11)
+    n = 4000
+    w = r.choice([1, 2, 3, 5, 8, 9, 13, 16, 17, 31, 32, 33, 64, 100, 200, 256], n)
+    h = r.choice([1, 2, 4, 6, 7, 15, 16, 17, 32, 33, 64, 129, 256], n)
+    x0 = (r.random(n) * (257 - w)).astype(np.int64)
+    y0 = (r.random(n) * (257 - h)).astype(np.int64)
+    trim = r.integers(0, 1 << 32, n, dtype=np.uint64)
+    trim[::5] = 0
+    trim[1::7] = 0xFFFFFFFF
+    packed = (x0 | (y0 << 8) | ((w - 1) << 16) | ((h - 1) << 24)).astype(np.uint64)
+    out = subprocess.run([exe], input="".join(f"{int(p)} {int(t)}\n" for p, t in zip(packed, trim)), capture_output=True, text=True, check=True).stdout.split("\n")
+    rshape = np.stack([packed, trim], 1).astype(np.uint32)
+    gx = 256
+    for k in range(n):
+        tx, ty = np.meshgrid(np.arange(x0[k], x0[k] + w[k]), np.arange(y0[k], y0[k] + h[k]))
+        tiles = (ty * gx + tx).reshape(-1)
+        want = util.trim_kept(rshape, np.full(tiles.shape, k), tiles, gx)
+        got = np.frombuffer(out[k].encode(), np.uint8) == ord("1")
+        assert np.array_equal(got, want), (k, int(w[k]), int(h[k]), hex(int(trim[k])))
