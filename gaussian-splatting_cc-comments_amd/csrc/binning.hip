@@ -121,7 +121,7 @@ __global__ void __launch_bounds__(GSR_PREPROCESS_BLOCK) gsr_duplicate_keys_kerne
 	const uint32_t off = incl - tiles;
 	// the backward blend addresses its per-(Gaussian,tile) gradient slots with this; a 4-byte scatter into a dense
 	// 4*P-byte array that the caches absorb (into the 48-byte splat records it cost 2x write amplification)
-	if (tiles && g.status[3] == 0u) g.slot_base[idx] = off;   // (status word 3: the bucket depth sort has numbered the slots already, in index order)
+	// (the gradient slots are numbered in index order before the depth sort, sort.hip: `off` only places this kernel's keys)
 	const uint32_t wave_first = __shfl(off, 0, 64);
 	const uint32_t wave_total = __shfl(incl, 63, 64) - wave_first;
 	s_own[wave][lane] = make_uint4(off - wave_first, rmin, w, idx);

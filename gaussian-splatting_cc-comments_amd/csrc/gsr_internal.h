@@ -35,7 +35,7 @@ struct GsrGeometry {
 	uint32_t* tiles_touched;
 	uint2* rect;               // dense copy of the tile rectangle {x | y << 16, w | h << 16}: what the depth-ordered kernels gather
 	uint2* rshape;             // {rectangle in one word, trim word} (gsr_rect_trim.h): what the depth sort carries along and the column-pair binning reads
-	uint32_t* slot_base;       // first (Gaussian,tile) gradient slot: exclusive prefix of tiles_touched in index order (status word 3) or in depth order
+	uint32_t* slot_base;       // first (Gaussian,tile) gradient slot: exclusive prefix of tiles_touched in index order (final once status word 3 is set)
 	uint8_t* clamped;
 	float* sh_ddir;            // [9][P] d(colour channel c)/d(unit view direction) of the visible Gaussians (plane 3c + {x,y,z})
 	uint32_t* status;             // GSR_STATUS_* words
@@ -155,6 +155,7 @@ void gsr_launch_tilebin_row_scatter(GsrGeometry g, int P, GsrBinning b, int64_t 
 int gsr_radix_num_passes(int nbits_total);
 size_t gsr_radix_table_bytes(size_t n);
 size_t gsr_radix_clear_words(size_t n);  // leading words of the table that the producer of the keys must zero
+void gsr_launch_slot_base_finish(uint32_t* slot_base, const uint32_t* block_tiles, uint32_t* status, size_t n, hipStream_t s);
 void gsr_radix_sort_passes(void* k0, uint32_t* v0, void* k1, uint32_t* v1, size_t n, int nbits_total, int npass_total,
                            int pass_first, int pass_count, void* table_mem, const uint32_t* bias, int key_bytes, hipStream_t s);
 void gsr_radix_sort_u32(void* k0, uint32_t* v0, void* k1, uint32_t* v1, size_t n, int nbits_total, void* table_mem,
@@ -163,7 +164,9 @@ void gsr_radix_top_pass(const uint32_t* k0, uint32_t* k1, const uint2* rec_in, u
                         uint32_t* slot_base, const uint32_t* block_tiles, uint32_t* status);
 int gsr_radix_top_chunks(size_t n);
 // depthsort.hip: depth order in three launches (top-digit buckets, then every bucket sorted inside LDS) for up to this many Gaussians
+#ifndef GSR_BUCKET_SORT_MAX_P
 #define GSR_BUCKET_SORT_MAX_P (2 << 20)
+#endif
 bool gsr_bucket_sort_applies(int P);
 void gsr_launch_depth_bucket_sort(GsrGeometry g, int P, uint4* seg, hipStream_t s);
 // bytes per tile key of an instance-sized sort: 2 when every tile id fits 16 bits AND the sort runs the instance-sized

@@ -55,6 +55,64 @@ __device__ __forceinline__ size_t gsr_sort_index(int block, int wave, int it, in
 // to the chunk (super-chunk) sums once, from registers: every address of those rows otherwise takes 64 (4 096) adders, which
 // serialise in the L2 (C5, the depth sort of 6 M Gaussians in 5 860 blocks: three-level tables).  1 for small sorts, whose
 // histogram kernels are a few microseconds of latency.
+// The Gaussians' first gradient slots become global: the preprocess kernel left slot_base[i] = exclusive scan of tiles_touched inside its
+// workgroup of GSR_PREPROCESS_BLOCK Gaussians and the workgroups' totals in block_tiles; the TILE_ Gaussians of block blockIdx.x add the
+// totals of every workgroup in front of theirs -- every workgroup here sums those up itself (<= P / 256 words, 16 loads in flight per
+// thread), as cheap as the walk of the offset tables and without a scan kernel of its own.  Index order: see preprocess.hip.  Called by all
+// GSR_SORT_THREADS threads of a workgroup that owns block blockIdx.x.
+template <int TILE_>
+__device__ __forceinline__ void gsr_slot_base_finish(uint32_t* __restrict__ slot_base, const uint32_t* __restrict__ block_tiles, uint32_t* __restrict__ status, size_t n)
+{
+	constexpr int SUB = TILE_ / GSR_PREPROCESS_BLOCK;
+	static_assert(TILE_ % GSR_PREPROCESS_BLOCK == 0, "a block must hold whole preprocess workgroups");
+	__shared__ uint32_t s_part[GSR_SORT_THREADS / 64], s_sub[SUB > 0 ? SUB : 1];
+	const int nb_all = (int)((n + GSR_PREPROCESS_BLOCK - 1) / GSR_PREPROCESS_BLOCK);
+	const int nb_before = (int)blockIdx.x * SUB;
+	uint32_t part = 0;
+	for (int j0 = 0; j0 < nb_before; j0 += 16 * GSR_SORT_THREADS) {
+		uint32_t t[16];
+#pragma unroll
+		for (int u = 0; u < 16; u++) {
+			const int j = j0 + u * GSR_SORT_THREADS + (int)threadIdx.x;
+			t[u] = j < nb_before ? block_tiles[j] : 0u;
+		}
+#pragma unroll
+		for (int u = 0; u < 16; u++) part += t[u];
+	}
+	const uint32_t own = ((int)threadIdx.x < SUB && nb_before + (int)threadIdx.x < nb_all) ? block_tiles[nb_before + threadIdx.x] : 0u;
+#pragma unroll
+	for (int off = 32; off > 0; off >>= 1) part += (uint32_t)__shfl_xor(part, off, 64);
+	if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = part;
+	__syncthreads();
+	if ((int)threadIdx.x < SUB) {   // (SUB <= 64: one wave) first slot of this block's sub-block `threadIdx.x`
+		uint32_t before = 0;
+#pragma unroll
+		for (int w = 0; w < GSR_SORT_THREADS / 64; w++) before += s_part[w];
+		uint32_t incl = own;
+#pragma unroll
+		for (int off = 1; off < SUB; off <<= 1) {
+			const uint32_t t = __shfl_up(incl, off, 64);
+			if ((int)threadIdx.x >= off) incl += t;
+		}
+		s_sub[threadIdx.x] = before + incl - own;
+	}
+	__syncthreads();
+	const size_t first = (size_t)blockIdx.x * TILE_;
+	for (int e0 = 4 * (int)threadIdx.x; e0 < TILE_; e0 += 4 * GSR_SORT_THREADS) {   // four consecutive Gaussians per thread: one sub-block
+		const uint32_t add = s_sub[e0 / GSR_PREPROCESS_BLOCK];
+		if (first + e0 + 3 < n) {
+			uint4* q = reinterpret_cast<uint4*>(slot_base + first + e0);
+			uint4 v = *q;
+			v.x += add; v.y += add; v.z += add; v.w += add;
+			*q = v;
+		} else {
+			for (int c = 0; c < 4; c++)
+				if (first + e0 + c < n) slot_base[first + e0 + c] += add;
+		}
+	}
+	if (blockIdx.x == 0 && threadIdx.x == 0) status[3] = 1u;   // (gsr_internal.h: slot_base is final, index order)
+}
+
 template <int ITEMS, typename KeyT>
 __global__ void __launch_bounds__(GSR_SORT_THREADS) gsr_radix_hist_kernel(const KeyT* __restrict__ keys, size_t n,
                                                                           int shift, uint32_t mask,
@@ -67,60 +125,9 @@ __global__ void __launch_bounds__(GSR_SORT_THREADS) gsr_radix_hist_kernel(const 
 {
 	__shared__ uint32_t hist[GSR_SORT_RADIX];
 	__shared__ uint32_t s_bias[2];
-	// First kernel of the bucket depth sort only (slot_base != NULL; one block per workgroup): the Gaussians' first gradient slots
-	// become global.  The preprocess kernel left slot_base[i] = exclusive scan of tiles_touched inside its workgroup of
-	// GSR_PREPROCESS_BLOCK Gaussians and the workgroups' totals in block_tiles; this block's Gaussians add the totals of every
-	// workgroup in front of theirs -- every workgroup here sums those up itself (<= P / 256 words, 16 loads in flight per thread),
-	// as cheap as the walk of the offset tables and without a scan kernel of its own.  Index order: see preprocess.hip.
+	// First kernel of the bucket depth sort only (slot_base != NULL; one block per workgroup): the gradient slots' numbering becomes global
 	if (slot_base) {
-		constexpr int TILE_ = GSR_SORT_THREADS * ITEMS, SUB = TILE_ / GSR_PREPROCESS_BLOCK;
-		static_assert(TILE_ % GSR_PREPROCESS_BLOCK == 0 || sizeof(KeyT) != 4, "a sort block must hold whole preprocess workgroups");
-		__shared__ uint32_t s_part[GSR_SORT_THREADS / 64], s_sub[SUB > 0 ? SUB : 1];
-		const int nb_all = (int)((n + GSR_PREPROCESS_BLOCK - 1) / GSR_PREPROCESS_BLOCK);
-		const int nb_before = (int)blockIdx.x * SUB;
-		uint32_t part = 0;
-		for (int j0 = 0; j0 < nb_before; j0 += 16 * GSR_SORT_THREADS) {
-			uint32_t t[16];
-#pragma unroll
-			for (int u = 0; u < 16; u++) {
-				const int j = j0 + u * GSR_SORT_THREADS + (int)threadIdx.x;
-				t[u] = j < nb_before ? block_tiles[j] : 0u;
-			}
-#pragma unroll
-			for (int u = 0; u < 16; u++) part += t[u];
-		}
-		const uint32_t own = ((int)threadIdx.x < SUB && nb_before + (int)threadIdx.x < nb_all) ? block_tiles[nb_before + threadIdx.x] : 0u;
-#pragma unroll
-		for (int off = 32; off > 0; off >>= 1) part += (uint32_t)__shfl_xor(part, off, 64);
-		if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = part;
-		__syncthreads();
-		if ((int)threadIdx.x < SUB) {   // (SUB <= 64: one wave) first slot of this block's sub-block `threadIdx.x`
-			uint32_t before = 0;
-#pragma unroll
-			for (int w = 0; w < GSR_SORT_THREADS / 64; w++) before += s_part[w];
-			uint32_t incl = own;
-#pragma unroll
-			for (int off = 1; off < SUB; off <<= 1) {
-				const uint32_t t = __shfl_up(incl, off, 64);
-				if ((int)threadIdx.x >= off) incl += t;
-			}
-			s_sub[threadIdx.x] = before + incl - own;
-		}
-		__syncthreads();
-		const size_t first = (size_t)blockIdx.x * TILE_;
-		for (int e0 = 4 * (int)threadIdx.x; e0 < TILE_; e0 += 4 * GSR_SORT_THREADS) {   // four consecutive Gaussians per thread: one sub-block
-			const uint32_t add = s_sub[e0 / GSR_PREPROCESS_BLOCK];
-			if (first + e0 + 3 < n) {
-				uint4* q = reinterpret_cast<uint4*>(slot_base + first + e0);
-				uint4 v = *q;
-				v.x += add; v.y += add; v.z += add; v.w += add;
-				*q = v;
-			} else {
-				for (int c = 0; c < 4; c++)
-					if (first + e0 + c < n) slot_base[first + e0 + c] += add;
-			}
-		}
-		if (blockIdx.x == 0 && threadIdx.x == 0) status[3] = 1u;   // (gsr_internal.h: slot_base is final, index order)
+		if constexpr (sizeof(KeyT) == 4 && (GSR_SORT_THREADS * ITEMS) % GSR_PREPROCESS_BLOCK == 0) gsr_slot_base_finish<GSR_SORT_THREADS * ITEMS>(slot_base, block_tiles, status, n);
 	}
 	const GsrKeyBias kb = gsr_sort_bias(bias, s_bias);
 	const bool biased = bias != nullptr;
@@ -488,4 +495,19 @@ void gsr_radix_sort_u32(void* k0, uint32_t* v0, void* k1, uint32_t* v1, size_t n
 	if (n == 0 || npass == 0) { *result_in_first = 1; return; }
 	if (clear_table) (void)hipMemsetAsync(table_mem, 0, gsr_radix_clear_words(n) * sizeof(uint32_t), s);
 	gsr_radix_sort_passes(k0, v0, k1, v1, n, nbits_total, npass, 0, npass, table_mem, nullptr, key_bytes, s);
+}
+
+// The same numbering for lists that take the global radix passes (beyond GSR_BUCKET_SORT_MAX_P Gaussians, GSR_DEBUG_RADIX_DEPTH): a kernel
+// of its own in front of them (the passes' first histogram kernel owns several blocks per workgroup).
+__global__ void __launch_bounds__(GSR_SORT_THREADS) gsr_slot_base_finish_kernel(uint32_t* __restrict__ slot_base, const uint32_t* __restrict__ block_tiles,
+                                                                                uint32_t* __restrict__ status, size_t n)
+{
+	gsr_slot_base_finish<GSR_SORT_THREADS * GSR_SORT_ITEMS_SMALL>(slot_base, block_tiles, status, n);
+}
+
+void gsr_launch_slot_base_finish(uint32_t* slot_base, const uint32_t* block_tiles, uint32_t* status, size_t n, hipStream_t s)
+{
+	if (n == 0) return;
+	const size_t tile = (size_t)GSR_SORT_THREADS * GSR_SORT_ITEMS_SMALL;
+	hipLaunchKernelGGL(gsr_slot_base_finish_kernel, dim3((unsigned)((n + tile - 1) / tile)), dim3(GSR_SORT_THREADS), 0, s, slot_base, block_tiles, status, n);
 }

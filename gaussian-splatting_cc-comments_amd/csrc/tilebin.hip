@@ -212,11 +212,10 @@ __device__ __forceinline__ void tb_expand_group(uint32_t d0, uint32_t len, uint3
 // ---- pass 1, histogram: per 1024 depth-ordered Gaussians --------------------------------------------
 // Also leaves the Gaussians' rectangles and ids in depth order (seg: the scatter kernel then starts from one coalesced
 // 16-byte load per Gaussian instead of the chain status word -> permutation -> 8-byte gather; perm == NULL: the bucket depth
-// sort has written seg already, and this kernel starts from that coalesced load too) and the workgroup's tile count
-// (the scatter kernel takes the prefix sums for the gradient-slot numbering), and records where the depth sort left its
+// sort has written seg already, and this kernel starts from that coalesced load too), and records where the depth sort left its
 // result.  Runs in forward stage 1, behind the depth sort, while the host waits for the count.
 __global__ void __launch_bounds__(TB_THREADS) gsr_tb_col_hist_kernel(const uint32_t* __restrict__ perm, const uint2* __restrict__ rect, int P,
-                                                                     uint32_t* __restrict__ block_sums, uint32_t* __restrict__ table, int nblocks,
+                                                                     uint32_t* __restrict__ table, int nblocks,
                                                                      uint32_t* __restrict__ chunk_sums, int nchunks, uint4* __restrict__ seg,
                                                                      uint32_t* __restrict__ status, uint32_t result_in_alt, int blocks_per_wg)
 {
@@ -251,7 +250,6 @@ __global__ void __launch_bounds__(TB_THREADS) gsr_tb_col_hist_kernel(const uint3
 			}
 		}
 		__syncthreads();
-		uint32_t tiles = 0;
 #pragma unroll
 		for (int q = 0; q < TB_GROUPS; q++) {
 			const int i = block * TB_BLOCK + wave * (64 * TB_GROUPS) + q * 64 + lane;
@@ -263,17 +261,13 @@ __global__ void __launch_bounds__(TB_THREADS) gsr_tb_col_hist_kernel(const uint3
 				atomicAdd(&diff[x0 + lead], 1);
 				atomicAdd(&diff[x0 + lead + wt], -1);
 			}
-			tiles += w * h;   // (the gradient slots are numbered over the whole rectangle)
 		}
 		__syncthreads();
 		// difference array (+1 at the first column, -1 behind the last) -> prefix sum over the digits = pairs per column
 		const uint32_t c = (uint32_t)diff[threadIdx.x];
-		const uint32_t cnt = gsr_excl_scan_256(c, wsum) + c;   // (wrapping arithmetic: the prefix sums themselves are >= 0)
+		const uint32_t cnt = gsr_excl_scan_256(c, wsum) + c;   // (wrapping arithmetic: the prefix sums themselves are >= 0; ends with a barrier: diff may be rewritten)
 		table[(size_t)block * TB_RADIX + threadIdx.x] = cnt;
 		acc += cnt;
-		uint32_t tot;
-		(void)gsr_excl_scan_256(tiles, wsum, &tot);   // (ends with a barrier: diff may be rewritten)
-		if (threadIdx.x == 0) block_sums[block] = tot;
 	}
 	if (acc) {
 		atomicAdd(&chunk_sums[(size_t)(block0 / GSR_SORT_CHUNK) * TB_RADIX + threadIdx.x], acc);
@@ -284,57 +278,37 @@ __global__ void __launch_bounds__(TB_THREADS) gsr_tb_col_hist_kernel(const uint3
 
 // ---- pass 1, scatter ------------------------------------------------------------------------------
 // Output: column pairs sorted by tile column, inside a column in depth order: (y0 | (h - 1) << 8, Gaussian id) as one 8-byte word.
-// Also: the Gaussians' first gradient slots (slot_base, depth-ordered numbering) unless the bucket depth sort has numbered them in
-// index order already (status word 3), pass 1's digit totals for pass 2's
-// workgroup map (workgroup 0), and zeroes for pass 2's chunk sums.
+// Also: pass 1's digit totals for pass 2's workgroup map (workgroup 0), and zeroes for pass 2's chunk sums.  (Until round 4 this
+// kernel also numbered the gradient slots, in depth order; they are numbered in index order now, before the depth sort: sort.hip.)
 __global__ void __launch_bounds__(TB_THREADS) gsr_tb_col_scatter_kernel(const uint4* __restrict__ seg, int P, int nblocks,
-                                                                        const uint32_t* __restrict__ block_sums,
                                                                         const uint32_t* __restrict__ table, const uint32_t* __restrict__ chunk_sums,
-                                                                        int nchunks, uint32_t* __restrict__ slot_base,
+                                                                        int nchunks,
                                                                         uint32_t* __restrict__ col_totals, uint2* __restrict__ cpair, uint32_t capacity,
-                                                                        uint32_t* __restrict__ clear, size_t clear_words, const uint32_t* __restrict__ status)
+                                                                        uint32_t* __restrict__ clear, size_t clear_words)
 {
 	__shared__ __attribute__((aligned(16))) unsigned long long s_mask[TB_WAVES][TB_RADIX];  // the walk's partial sums first, then the ranking's peer masks
 	__shared__ __attribute__((aligned(16))) uint32_t wcount[TB_WAVES][TB_RADIX];
 	__shared__ __attribute__((aligned(16))) int32_t wdiff[TB_WAVES][TB_RADIX + 4];
 	__shared__ TbOwnCol s_own[TB_WAVES][64];
 	__shared__ uint32_t s_flag[TB_WAVES][64];
-	__shared__ uint32_t wsum[TB_WAVES], gsum[TB_WAVES * TB_GROUPS];
+	__shared__ uint32_t wsum[TB_WAVES];
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	for (size_t w = (size_t)blockIdx.x * TB_THREADS + threadIdx.x; w < clear_words; w += (size_t)gridDim.x * TB_THREADS) clear[w] = 0u;
 	s_flag[wave][lane] = 0u;
-	const bool slot_final = status[3] != 0u;   // the bucket depth sort has numbered the gradient slots already (index order): uniform
 	// Workgroup w takes the consecutive blocks [w per, (w + 1) per) -- one block while every block of the launch is resident at once
 	// (up to ~1 M Gaussians), several beyond -- and walks the offset tables for the first of them only (see pass 2's scatter)
 	const int per = (nblocks + (int)gridDim.x - 1) / (int)gridDim.x;
 	const int blk_first = (int)blockIdx.x * per, blk_end = min(blk_first + per, nblocks);
 	if (blk_first >= blk_end) return;   // (uniform)
 
-	// tile count of all blocks in front (depth order): every workgroup adds the block sums up itself
-	uint32_t before_tiles = 0;
-	for (uint32_t b0 = 0; b0 < (uint32_t)blk_first; b0 += 8 * TB_THREADS) {
-		uint32_t t[8];
-#pragma unroll
-		for (int j = 0; j < 8; j++) {
-			const uint32_t b = b0 + j * TB_THREADS + threadIdx.x;
-			t[j] = b < (uint32_t)blk_first ? block_sums[b] : 0u;
-		}
-#pragma unroll
-		for (int j = 0; j < 8; j++) before_tiles += t[j];
-	}
 	uint32_t v, before;
 	gsr_radix_walk_256<TB_WALK_ROWS>(table, chunk_sums, nchunks, nchunks, blk_first, reinterpret_cast<uint32_t*>(&s_mask[0][0]), v, before);
 	if (blockIdx.x == 0) col_totals[threadIdx.x] = v;
 	const uint32_t dbase = gsr_excl_scan_256(v, wsum);
-	uint32_t tiles_front;
-	(void)gsr_excl_scan_256(before_tiles, wsum, &tiles_front);   // (its sum over the threads)
 	uint32_t round = 0u;
 
 	for (int blk = blk_first; blk < blk_end; blk++) {
-		if (blk != blk_first) {   // the predecessor's own counts move the offsets on
-			before += table[(size_t)(blk - 1) * TB_RADIX + threadIdx.x];
-			tiles_front += block_sums[blk - 1];
-		}
+		if (blk != blk_first) before += table[(size_t)(blk - 1) * TB_RADIX + threadIdx.x];   // the predecessor's own counts move the offsets on
 		const uint32_t gbase = dbase + before;
 		uint4 sg[TB_GROUPS];
 #pragma unroll
@@ -342,20 +316,17 @@ __global__ void __launch_bounds__(TB_THREADS) gsr_tb_col_scatter_kernel(const ui
 			const int i = blk * TB_BLOCK + wave * (64 * TB_GROUPS) + q * 64 + lane;
 			sg[q] = i < P ? seg[i] : make_uint4(GSR_RECT_NONE, 0u, 0u, 0u);
 		}
-		uint32_t id[TB_GROUPS], d0[TB_GROUPS], len[TB_GROUPS], key[TB_GROUPS], trim[TB_GROUPS], tiles[TB_GROUPS], incl_t[TB_GROUPS];
+		uint32_t id[TB_GROUPS], d0[TB_GROUPS], len[TB_GROUPS], key[TB_GROUPS], trim[TB_GROUPS];
 #pragma unroll
 		for (int q = 0; q < TB_GROUPS; q++) {
 			uint32_t x0, y0, w, h, lead, wt;
 			gsr_rect_unpack(sg[q].x, x0, y0, w, h);
 			gsr_trim_columns(sg[q].y, w, h, lead, wt);
 			id[q] = sg[q].z;
-			tiles[q] = w * h;
 			len[q] = wt;              // one element per column that keeps a row
 			d0[q] = x0 + lead;
 			trim[q] = sg[q].y;
 			key[q] = y0 | ((h - 1u) << 8) | (lead << 16) | (gsr_trim_col_shift(w) << 24) | (gsr_trim_row_shift(h) << 27);
-			incl_t[q] = tb_wave_incl_scan(tiles[q]);
-			if (lane == 63) gsum[wave * TB_GROUPS + q] = incl_t[q];
 		}
 		tb_wave_counts(d0, len, wdiff[wave], wcount[wave]);
 		__syncthreads();
@@ -363,13 +334,6 @@ __global__ void __launch_bounds__(TB_THREADS) gsr_tb_col_scatter_kernel(const ui
 		reinterpret_cast<uint4*>(s_mask[wave])[lane] = make_uint4(0u, 0u, 0u, 0u);
 		reinterpret_cast<uint4*>(s_mask[wave])[64 + lane] = make_uint4(0u, 0u, 0u, 0u);
 		tb_wave_bases(wcount, gbase);
-		// first gradient slot of every Gaussian with tiles = tiles of everything in front of it in depth order
-#pragma unroll
-		for (int q = 0; q < TB_GROUPS; q++) {
-			uint32_t base = tiles_front;
-			for (int G = 0; G < wave * TB_GROUPS + q; G++) base += gsum[G];
-			if (!slot_final && tiles[q]) slot_base[id[q]] = base + incl_t[q] - tiles[q];
-		}
 		__syncthreads();
 #pragma unroll 1
 		for (int q = 0; q < TB_GROUPS; q++)
@@ -564,7 +528,7 @@ void gsr_launch_tilebin_col_hist(GsrGeometry g, int P, int result_in_alt, hipStr
 	while (per < GSR_SORT_CHUNK && t.nblocks / (2 * per) >= 1024) per *= 2;
 	const uint32_t* perm = seg_ready ? nullptr : (result_in_alt ? g.perm_alt : g.perm);
 	hipLaunchKernelGGL(gsr_tb_col_hist_kernel, dim3((t.nblocks + per - 1) / per), dim3(TB_THREADS), 0, s, perm, g.rshape, P,
-	                   g.sorted_block_sums, t.table, t.nblocks, t.chunk_sums, t.nchunks, t.seg, g.status, (uint32_t)result_in_alt, per);
+	                   t.table, t.nblocks, t.chunk_sums, t.nchunks, t.seg, g.status, (uint32_t)result_in_alt, per);
 }
 
 // the sorted column pairs: 8 bytes each, in the two arrays of the binning blob that only the tile sort uses (point_list_alt and,
@@ -585,9 +549,9 @@ void gsr_launch_tilebin_col_scatter(GsrGeometry g, int P, GsrBinning b, int64_t 
 {
 	const TbColTable t = tb_col_table(g.col_table, P);
 	const int grid = t.nblocks < 256 * 4 ? t.nblocks : 256 * 4;   // what the chip holds at once (116 VGPRs: four workgroups per CU)
-	hipLaunchKernelGGL(gsr_tb_col_scatter_kernel, dim3(grid), dim3(TB_THREADS), 0, s, t.seg, P, t.nblocks, g.sorted_block_sums, t.table, t.chunk_sums,
-	                   t.nchunks, g.slot_base, t.totals, tb_pairs(b), tb_pair_capacity(b), (uint32_t*)b.sort_table,
-	                   gsr_tilebin_row_clear_words((size_t)R), (const uint32_t*)g.status);
+	hipLaunchKernelGGL(gsr_tb_col_scatter_kernel, dim3(grid), dim3(TB_THREADS), 0, s, t.seg, P, t.nblocks, t.table, t.chunk_sums,
+	                   t.nchunks, t.totals, tb_pairs(b), tb_pair_capacity(b), (uint32_t*)b.sort_table,
+	                   gsr_tilebin_row_clear_words((size_t)R));
 }
 
 void gsr_launch_tilebin_row_hist(GsrGeometry g, int P, GsrBinning b, int64_t R, hipStream_t s)

@@ -87,8 +87,8 @@ typedef struct {
 	size_t perm_alt;       /* [P] u32 sort ping-pong */
 	size_t tiles_touched;  /* [P] u32 */
 	size_t rect;           /* [P] uint2: tile rectangle {min x | min y << 16, width | height << 16} (dense copy of the record's) */
-	size_t slot_base;      /* [P] u32: first gradient slot of the Gaussian: exclusive prefix of tiles_touched in index order (status word 3
-	                          = 1: up to 2 Mi Gaussians) or in (depth, id) order (status word 3 = 0); a Gaussian's slots are contiguous */
+	size_t slot_base;      /* [P] u32: first gradient slot of the Gaussian: exclusive prefix of tiles_touched in index order (status word 3 = 1
+	                          once forward stage 1 has run); a Gaussian's slots are contiguous */
 	size_t clamped;        /* [P] u8 bit c set = colour channel c was clamped at 0 */
 	size_t sh_ddir;        /* [9][P] f32 d(colour channel c)/d(unit view direction x,y,z) of the visible Gaussians, left by the forward so
 	                          that the backward does not read the SH rows again (backward.cu:98-132) */
