@@ -498,16 +498,19 @@ void gsr_radix_sort_u32(void* k0, uint32_t* v0, void* k1, uint32_t* v1, size_t n
 }
 
 // The same numbering for lists that take the global radix passes (beyond GSR_BUCKET_SORT_MAX_P Gaussians, GSR_DEBUG_RADIX_DEPTH): a kernel
-// of its own in front of them (the passes' first histogram kernel owns several blocks per workgroup).
+// of its own in front of them (the passes' first histogram kernel owns several blocks per workgroup).  Every workgroup adds up the totals
+// in front of it, so the blocks are large here -- 64 preprocess workgroups, 16 384 Gaussians: at 6 M Gaussians 366 workgroups read 17 MB
+// of totals between them; with blocks of 1 024 it was 5 860 workgroups and 274 MB, 0.10 ms on the path of the depth sort.
+#define GSR_SLOT_FINISH_TILE (64 * GSR_PREPROCESS_BLOCK)
 __global__ void __launch_bounds__(GSR_SORT_THREADS) gsr_slot_base_finish_kernel(uint32_t* __restrict__ slot_base, const uint32_t* __restrict__ block_tiles,
                                                                                 uint32_t* __restrict__ status, size_t n)
 {
-	gsr_slot_base_finish<GSR_SORT_THREADS * GSR_SORT_ITEMS_SMALL>(slot_base, block_tiles, status, n);
+	gsr_slot_base_finish<GSR_SLOT_FINISH_TILE>(slot_base, block_tiles, status, n);
 }
 
 void gsr_launch_slot_base_finish(uint32_t* slot_base, const uint32_t* block_tiles, uint32_t* status, size_t n, hipStream_t s)
 {
 	if (n == 0) return;
-	const size_t tile = (size_t)GSR_SORT_THREADS * GSR_SORT_ITEMS_SMALL;
+	const size_t tile = (size_t)GSR_SLOT_FINISH_TILE;
 	hipLaunchKernelGGL(gsr_slot_base_finish_kernel, dim3((unsigned)((n + tile - 1) / tile)), dim3(GSR_SORT_THREADS), 0, s, slot_base, block_tiles, status, n);
 }
