@@ -571,14 +571,16 @@ static int gsr_forward_preprocess_impl(int P, int D, int M, int width, int heigh
 			if (col_pairs) gsr_launch_tilebin_col_hist(a.g, P, 0, s, true);
 			else gsr_launch_sorted_block_sums(a.g, P, 0, s);
 		} else {
-			// (the gradient slots are numbered in index order here too -- a kernel of its own: the bucket sort's first kernel does it on the way)
-			gsr_launch_slot_base_finish(a.g.slot_base, a.g.block_tiles, a.g.status, (size_t)P, s);
 			gsr_radix_sort_passes(a.g.depth_keys, a.g.perm, a.g.depth_keys_alt, a.g.perm_alt, (size_t)P, 32, 4, 0, 3, a.g.sort_table, bias, 4, s);
 			// ... and so are the block sums over the three-pass result (the common case) -- with them, for images the column-pair
 			// binning handles, the histogram of its first pass (tilebin.hip): the stream then holds work until the host, back from
 			// the wait below, has launched stage 2.  A fourth pass redoes them.
 			if (col_pairs) gsr_launch_tilebin_col_hist(a.g, P, 1, s);
 			else gsr_launch_sorted_block_sums(a.g, P, 1, s);
+			// The gradient slots are numbered in index order here too (the bucket sort's first kernel does it on the way): a kernel of its
+			// own, and LAST in stage 1 -- nothing reads slot_base before the backward, and in front of the passes it ran beside the colour
+			// kernel, which streams the SH rows: 48 MB took 0.10-0.125 ms there at 6 M Gaussians, 0.025 alone.
+			gsr_launch_slot_base_finish(a.g.slot_base, a.g.block_tiles, a.g.status, (size_t)P, s);
 		}
 	}
 	if ((rc = gsr_stage_done(s, debug, "depth_sort"))) return rc;
