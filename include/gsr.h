@@ -94,10 +94,12 @@ typedef struct {
 	                          that the backward does not read the SH rows again (backward.cu:98-132) */
 	size_t status;         /* u32 device status words (0: prefiltered trap; 2: depth order in the _alt pair; 3: slots numbered in index order; 4..67: partial instance
 	                          counts; 68..131 / 132..195: partial maxima of ~depth key / depth key of the visible Gaussians) */
-	size_t scan_temp;      /* per-workgroup tile counts in depth order, then the preprocess workgroups' tile counts in index order */
+	size_t scan_temp;      /* per-workgroup tile counts in depth order (tile-sort path: the key emission's offsets), then the preprocess
+	                          workgroups' tile counts in index order (the gradient slots' numbering) */
 	size_t sort_table;     /* radix histogram table of the depth sort */
 	size_t col_table;      /* column-pair binning, pass 1 (by tile column): chunk sums, per-workgroup digit rows, 256 digit totals, the
-	                          Gaussians' {rectangle, id} records in depth order and (bucket depth sort) in bucket order, 16 B each */
+	                          Gaussians' records {rectangle in one word, trim word, id, -} (see rshape) in depth order and (bucket depth sort) in
+	                          bucket order, 16 B each */
 	size_t rshape;         /* [P] uint2 {rectangle in one word: x | y << 8 | (w - 1) << 16 | (h - 1) << 24, 0xFFFFFFFF = no tiles; trim word:
 	                          a nibble per tile column of the rectangle (per group of 2 .. 32 columns when it is wider than 8), rows left out at its top
 	                          (2 bits) and bottom (2 bits; in units of 2 .. 16 rows when it is taller than 16)}: what the

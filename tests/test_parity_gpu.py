@@ -31,8 +31,9 @@ def check_forward(h, o, cam):
     np.testing.assert_array_equal(h["tiles_touched"], o["tiles_touched"])
     order = np.lexsort((np.arange(P), o["depths"].view(np.uint32) | np.where(o["radii"] > 0, 0, 0xFFFFFFFF).astype(np.uint32)))
     np.testing.assert_array_equal(h["perm"], order.astype(np.uint32))
-    # gradient slots: a Gaussian's first slot = exclusive prefix of tiles_touched -- in index order (what the reference's InclusiveSum
-    # gives, rasterizer_impl.cu:323) when the bucket depth sort numbered them, in (depth, id) order when the binning did
+    # gradient slots: a Gaussian's first slot = exclusive prefix of tiles_touched in index order (what the reference's InclusiveSum
+    # gives, rasterizer_impl.cu:323)
+    assert h["slots_in_index_order"] == 1
     if h["slots_in_index_order"]:
         tt = o["tiles_touched"].astype(np.int64)
         base = np.cumsum(tt) - tt

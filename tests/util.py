@@ -128,7 +128,8 @@ def unpack_state(cap, P, W, H, tile_sort=False):
     # status word 2: the depth sort ended in the ping-pong partners (three passes sufficed for the depth range)
     in_alt = int(geom[gl.status:gl.status + 16].view(np.uint32)[2])
     o["depth_sort_result_in_alt"] = in_alt
-    # status word 3: the gradient slots are numbered in INDEX order (the bucket depth sort did it); 0: in depth order (by the binning)
+    # status word 3: the gradient slots' numbering (index order: the exclusive prefix of tiles_touched) is final -- set by forward stage 1 on
+    # both depth-sort paths since the end of round 4 (rounds 1-3, and round 4's radix path at first, numbered them in depth order: 0)
     o["slots_in_index_order"] = int(geom[gl.status:gl.status + 16].view(np.uint32)[3])
     p_off, k_off = (gl.perm_alt, gl.depth_keys_alt) if in_alt else (gl.perm, gl.depth_keys)
     perm = geom[p_off:p_off + 4 * P].view(np.uint32)
